@@ -1,0 +1,284 @@
+/* yuki_hip.h — C ABI of the MI355X-native wavefront Path integrator.
+ *
+ * Drop-in boundary for the hot path of sndels/yuki: the private Rust trait
+ *
+ *     trait Integrator { fn li(..); fn render(&self, scratch, scene, camera,
+ *         sampler, accumulating, tile, tile_pixels, early_termination_predicate)
+ *         -> usize }                    (yuki/src/integrators/mod.rs:92-186)
+ *
+ * and the data its sibling traits describe (Sampler sampling/mod.rs:46-57,
+ * Material materials/mod.rs:20-27, Shape shapes/mod.rs:26-39, Light
+ * lights/mod.rs:29-37).  A Rust shim `impl Integrator for HipPath` binds exactly
+ * these entry points; our own host code (C++ wrapper
+ * yuki_hip.hpp, Python mirror yuki_amd/) and the parity tests call the same ones.
+ *
+ * Conventions
+ *   - plain C, caller-owned buffers, no hidden allocation handed back;
+ *   - every call returns a yk_status (the reference panics/asserts instead:
+ *     integrators/mod.rs:131,141 -> YK_ERR_INVALID_ARGUMENT);
+ *   - matrices are row-major float[16] (math/matrix.rs:16);
+ *   - radiance buffers are tightly packed RGB float triples (Spectrum<f32>,
+ *     math/spectrum.rs:45-55), tile-major, each tile row-major — the layout of
+ *     `tile_pixels[ty*tile_width+tx]` (integrators/mod.rs:177-182);
+ *   - the sampler seed is explicit (the reference draws it from thread_rng(),
+ *     sampling/uniform.rs:37 — quirk 20 of SURVEY.md).
+ */
+#ifndef YUKI_HIP_H
+#define YUKI_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YK_ABI_VERSION 1
+
+typedef enum yk_status {
+    YK_OK = 0,
+    YK_ERR_INVALID_ARGUMENT = 1, /* contract violation (reference: assert!/panic) */
+    YK_ERR_NO_DEVICE = 2,        /* HIP runtime / device unavailable */
+    YK_ERR_DEVICE = 3,           /* a HIP call failed; see yk_last_error */
+    YK_ERR_OUT_OF_MEMORY = 4,
+    YK_ERR_UNSUPPORTED = 5,      /* e.g. spheres / Whitted on the device path */
+    YK_ERR_BVH_BUILD = 6,        /* reference: assert_ne!(mid,start) bvh.rs:368 */
+    YK_ERR_CANCELLED = 7,        /* early_termination_predicate returned true */
+    YK_ERR_STACK_OVERFLOW = 8    /* traversal stack > 64, reference: assert bvh.rs:174 */
+} yk_status;
+
+/* ---- scene description: flattened, world space, caller owned, read only ---- */
+
+/* shapes/mesh.rs:7-43 — per `Mesh` flags (normals / uvs presence is per mesh) */
+typedef struct yk_mesh_desc {
+    uint8_t has_normals, has_uvs, swaps_handedness, pad;
+} yk_mesh_desc;
+
+/* shapes/sphere.rs:14-35 */
+typedef struct yk_sphere_desc {
+    float object_to_world[16];
+    float world_to_object[16];
+    float radius;
+    int32_t material;
+} yk_sphere_desc;
+
+/* materials/{matte,glass,metal,glossy}.rs with ConstantTexture inputs
+ * (textures/constant.rs) folded in */
+typedef enum yk_material_kind { YK_MAT_MATTE = 0, YK_MAT_GLASS = 1, YK_MAT_METAL = 2, YK_MAT_GLOSSY = 3 } yk_material_kind;
+typedef struct yk_material_desc {
+    uint32_t kind;
+    float a[3];     /* matte Kd | glass R | metal eta | glossy Rs */
+    float b[3];     /*          | glass T | metal k   |           */
+    float c;        /* matte sigma (radians) | glass eta | metal/glossy roughness */
+    uint32_t flags; /* bit0: remap_roughness */
+} yk_material_desc;
+
+/* lights/{point,spot,distant,rectangular}_light.rs — build with yk_make_*_light */
+typedef enum yk_light_kind { YK_LIGHT_POINT = 0, YK_LIGHT_SPOT = 1, YK_LIGHT_DISTANT = 2, YK_LIGHT_RECT = 3 } yk_light_kind;
+typedef struct yk_light_desc {
+    uint32_t kind;
+    float p[3]; /* point/spot position ; distant: direction w */
+    float i[3]; /* intensity (point/spot) | radiance (distant/rect) */
+    float cos_total_width, cos_falloff_start;
+    float world_to_light[16];      /* spot */
+    float sample_to_world[16];     /* rect */
+    float sample_to_world_inv[16]; /* rect */
+    float area;                    /* rect */
+} yk_light_desc;
+
+typedef enum yk_split_method { YK_SPLIT_SAH = 0, YK_SPLIT_MIDDLE = 1, YK_SPLIT_EQUAL_COUNTS = 2 } yk_split_method;
+
+/* scene/mod.rs:41-49 `Scene` + SceneLoadSettings (:25-39) */
+typedef struct yk_scene_desc {
+    uint32_t n_vertices;
+    const float* points;  /* 3*n_vertices, world space (Mesh::new pre-transforms, mesh.rs:27-33) */
+    const float* normals; /* 3*n_vertices or NULL */
+    const float* uvs;     /* 2*n_vertices or NULL */
+    uint32_t n_triangles;
+    const uint32_t* indices;       /* 3*n_triangles */
+    const uint32_t* tri_mesh;      /* n_triangles -> meshes[] */
+    const int32_t* tri_material;   /* n_triangles -> materials[] */
+    const int32_t* tri_area_light; /* n_triangles -> lights[] or -1 (Triangle.area_light, triangle.rs:22) */
+    uint32_t n_meshes;
+    const yk_mesh_desc* meshes;
+    uint32_t n_spheres; /* shapes are ordered: triangles, then spheres */
+    const yk_sphere_desc* spheres;
+    uint32_t n_materials;
+    const yk_material_desc* materials;
+    uint32_t n_lights;
+    const yk_light_desc* lights;
+    float background[3];
+    uint32_t split_method;       /* yk_split_method */
+    uint32_t max_shapes_in_node; /* scene/mod.rs:36 default 1 */
+} yk_scene_desc;
+
+/* camera.rs:19-22 `Camera` = two Transforms */
+typedef struct yk_camera {
+    float camera_to_world[16], camera_to_world_inv[16];
+    float raster_to_camera[16], raster_to_camera_inv[16];
+} yk_camera;
+
+/* camera.rs:24-30 `CameraParameters` + the film resolution Camera::new reads */
+typedef struct yk_camera_params {
+    float position[3], target[3], up[3];
+    uint32_t fov_axis; /* 0 = FoV::X, 1 = FoV::Y */
+    float fov_degrees;
+    uint16_t res_x, res_y;
+} yk_camera_params;
+
+/* sampling/mod.rs:16-19 `SamplerType` */
+typedef enum yk_sampler_kind { YK_SAMPLER_UNIFORM = 0, YK_SAMPLER_STRATIFIED = 1 } yk_sampler_kind;
+typedef struct yk_sampler_desc {
+    uint32_t kind;
+    uint32_t nx, ny; /* uniform: nx = pixel_samples ; stratified: pixel_samples.{x,y} */
+    uint32_t jitter; /* stratified jitter_samples */
+    uint64_t seed;   /* rng_seed */
+} yk_sampler_desc;
+
+/* integrators/mod.rs:33-40 `IntegratorType` */
+typedef enum yk_integrator_kind {
+    YK_INTEGRATOR_WHITTED = 0, /* not implemented on the device */
+    YK_INTEGRATOR_PATH = 1,
+    YK_INTEGRATOR_BVH_INTERSECTIONS = 2,
+    YK_INTEGRATOR_GEOMETRY_NORMALS = 3,
+    YK_INTEGRATOR_SHADING_NORMALS = 4
+} yk_integrator_kind;
+typedef struct yk_integrator_desc {
+    uint32_t kind;
+    uint32_t max_depth;   /* path.rs:20-23 Params */
+    uint32_t has_clamp;   /* indirect_clamp.is_some() */
+    float indirect_clamp;
+} yk_integrator_desc;
+
+/* film.rs:43-65 `FilmTile.bb` (Bounds2<u16>, max exclusive) */
+typedef struct yk_tile {
+    uint16_t x0, y0, x1, y1;
+} yk_tile;
+
+/* bvh.rs:536-556 — the reference's 32-byte node, exported for inspection/tests */
+typedef struct yk_bvh_node {
+    float bmin[3], bmax[3];
+    uint32_t a;     /* interior: second_child_index ; leaf: first_shape_index */
+    uint16_t count; /* leaf: shape_count */
+    uint8_t axis, is_leaf;
+} yk_bvh_node;
+
+typedef struct yk_scene_info {
+    uint64_t n_nodes, n_interior, n_shapes;
+    float bounds_min[3], bounds_max[3];
+    double build_seconds, upload_seconds;
+    uint64_t device_bytes;
+    uint32_t max_leaf_shapes, tree_depth;
+} yk_scene_info;
+
+typedef struct yk_render_stats {
+    uint64_t rays;          /* closest-hit rays == the reference's ray_count (path.rs:87) */
+    uint64_t shadow_rays;   /* any-hit rays, not part of the metric */
+    uint64_t samples;       /* camera samples rendered */
+    double seconds_total;   /* first launch -> film resolved (device time, HIP events) */
+    double seconds_trace;   /* summed duration of the closest-hit traversal launches */
+    double seconds_shadow;  /* summed duration of the any-hit traversal launches */
+    double seconds_shade;   /* summed duration of the shade (BSDF+NEE) launches */
+    uint32_t trace_launches, batches;
+} yk_render_stats;
+
+typedef struct yk_context yk_context;
+typedef struct yk_scene yk_scene;
+
+/* early_termination_predicate (integrators/mod.rs:129): polled between batches;
+ * returning non-zero aborts the render with YK_ERR_CANCELLED (tile contents
+ * undefined, as in render_worker.rs:252-255). */
+typedef int (*yk_cancel_fn)(void* user);
+
+/* ---- library / context ---------------------------------------------------- */
+uint32_t yk_abi_version(void);
+const char* yk_status_string(yk_status s);
+yk_status yk_context_create(int device, yk_context** out);
+void yk_context_destroy(yk_context* ctx);
+yk_status yk_last_error(const yk_context* ctx, char* buf, size_t cap);
+/* tuning knobs: "batch_paths" (paths in flight), "trace_variant", "block_size" ... */
+yk_status yk_context_set_option(yk_context* ctx, const char* key, int64_t value);
+
+/* ---- host-side restatements (no GPU needed) -------------------------------- */
+/* Camera::new, camera.rs:52-102 */
+yk_status yk_camera_init(const yk_camera_params* params, yk_camera* out);
+/* film_tiles / generate_tiles / outward_spiral, film.rs:299-376,409-475.
+ * Returns the number of tiles; writes min(cap, n) of them in spiral order. */
+size_t yk_film_tiles(uint16_t res_x, uint16_t res_y, uint16_t tile_dim, yk_tile* out, size_t cap);
+/* RectangularLight::new rectangular_light.rs:31-42, SpotLight::new spot_light.rs:20-36,
+ * PointLight::new point_light.rs:18-24 */
+yk_status yk_make_rect_light(const float light_to_world[16], const float light_to_world_inv[16], const float radiance[3],
+                             const float size[2], yk_light_desc* out);
+yk_status yk_make_spot_light(const float light_to_world[16], const float light_to_world_inv[16], const float intensity[3],
+                             float total_width_degrees, float falloff_start_degrees, yk_light_desc* out);
+yk_status yk_make_point_light(const float light_to_world[16], const float intensity[3], yk_light_desc* out);
+/* Film::update_tile (film.rs:210-282), host buffers: tile-major -> row-major film */
+yk_status yk_film_update_tiles(const yk_tile* tiles, size_t n_tiles, const float* tile_rgb, uint16_t res_x, uint16_t res_y,
+                               float* film_rgb);
+
+/* ---- scene ------------------------------------------------------------------ */
+/* BoundingVolumeHierarchy::new (bvh.rs:39-115) on the host, then upload.
+ * ctx may be NULL: host-only scene (BVH build/export without a GPU). */
+yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* desc, yk_scene** out);
+void yk_scene_destroy(yk_scene* scene);
+yk_status yk_scene_get_info(const yk_scene* scene, yk_scene_info* out);
+/* nodes: n_nodes entries in the reference's depth-first layout; shape_order:
+ * n_shapes source indices in leaf order (bvh.rs:96).  Either may be NULL. */
+yk_status yk_scene_export_bvh(const yk_scene* scene, yk_bvh_node* nodes, uint32_t* shape_order);
+
+/* ---- the hot path -------------------------------------------------------------- */
+/* Integrator::render for a batch of tiles (integrators/mod.rs:120-185, non-accumulating
+ * film).  out_rgb: host buffer, tile-major, 3 floats per pixel. */
+yk_status yk_render_tiles(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                          const yk_integrator_desc* integrator, const yk_tile* tiles, size_t n_tiles, float* out_rgb,
+                          yk_render_stats* stats, yk_cancel_fn cancel, void* user);
+/* Same, radiance left in device memory (d_out_rgb: device pointer, same layout)
+ * on `stream` (a hipStream_t, NULL = the context's stream).  Asynchronous unless
+ * stats != NULL. */
+yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const yk_camera* camera,
+                                 const yk_sampler_desc* sampler, const yk_integrator_desc* integrator, const yk_tile* tiles,
+                                 size_t n_tiles, void* d_out_rgb, void* stream, yk_render_stats* stats, yk_cancel_fn cancel,
+                                 void* user);
+/* Exactly the trait method: one tile, returns the ray count through *out_rays. */
+yk_status yk_render_tile(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                         const yk_integrator_desc* integrator, const yk_tile* tile, float* tile_pixels, uint64_t* out_rays);
+/* Film::update_tile on the device: scatter tile-major radiance into a row-major
+ * film (both device pointers).  Used on rank 0 after the RCCL gather. */
+yk_status yk_film_update_tiles_device(yk_context* ctx, const yk_tile* tiles, size_t n_tiles, const void* d_tile_rgb,
+                                      uint16_t res_x, uint16_t res_y, void* d_film_rgb, void* stream);
+/* Integrator::li (integrators/mod.rs:94-101) for n caller-supplied rays; the
+ * sampler is started at (pixel, sample_index) and advanced by `dimension`
+ * draws already consumed by the caller (2 for a camera ray). */
+yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* sampler, const yk_integrator_desc* integrator,
+                size_t n, const float* ray_o, const float* ray_d, const uint16_t* pixel_xy, const uint32_t* sample_index,
+                uint32_t dimension, float* out_li, uint32_t* out_ray_counts);
+
+/* ---- per-stage entry points (parity tests, profiling) ------------------------- */
+/* BoundingVolumeHierarchy::intersect (bvh.rs:160-232) for n host rays.
+ * out_shape: source shape index or -1; counters as IntersectionResult. */
+yk_status yk_trace_closest(yk_context* ctx, const yk_scene* scene, size_t n, const float* ray_o, const float* ray_d,
+                           const float* t_max /* NULL = inf */, int32_t* out_shape, float* out_t, float* out_bary /* 3n */,
+                           uint32_t* out_node_tests, uint32_t* out_node_hits, uint32_t* out_shape_tests);
+/* BoundingVolumeHierarchy::any_intersect (bvh.rs:235-302) */
+yk_status yk_trace_any(yk_context* ctx, const yk_scene* scene, size_t n, const float* ray_o, const float* ray_d,
+                       const float* t_max, const int32_t* area_light /* NULL = none */, uint8_t* out_hit);
+/* Sampler start_pixel_sample + draws, evaluated on the device */
+yk_status yk_sampler_sequence(yk_context* ctx, const yk_sampler_desc* sampler, uint16_t px, uint16_t py, uint32_t sample_index,
+                              const uint8_t* dims, size_t n_draws, float* out /* 2 per draw */);
+/* Camera::ray for every pixel of a tile at one sample index (camera.rs:105-114) */
+yk_status yk_camera_rays(yk_context* ctx, const yk_camera* camera, const yk_sampler_desc* sampler, const yk_tile* tile,
+                         uint32_t sample_index, float* out_o, float* out_d);
+/* device libm used by the kernels: fn 0 sin, 1 cos, 2 tan, 3 log, 4 acos, 5 atan2(x=y_in,y=x_in),
+ * 6 sqrt, 7 a/b, 8 f64-cross helper */
+yk_status yk_device_math(yk_context* ctx, int fn, size_t n, const float* a, const float* b, float* out);
+/* Bsdf::f and Bsdf::sample_f on the device for n (wo, wi|u) pairs against one material */
+yk_status yk_bsdf_eval(yk_context* ctx, const yk_material_desc* material, size_t n, const float* n_geom,
+                       const float* n_shading, const float* dpdu, const float* wo, const float* wi, float* out_f);
+yk_status yk_bsdf_sample(yk_context* ctx, const yk_material_desc* material, size_t n, const float* n_geom,
+                         const float* n_shading, const float* dpdu, const float* wo, const float* u, float* out8);
+
+size_t yk_sizeof(int what);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YUKI_HIP_H */

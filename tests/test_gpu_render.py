@@ -1,0 +1,161 @@
+"""GPU parity of the whole hot path: Integrator::render through the C ABI against
+the CPU oracle on the same scene, camera, sampler seed.
+
+Bar (BASELINE.json north_star): per-pixel radiance RMSE < 1e-4 vs the CPU
+reference.  Because every arithmetic step is restated operation for operation
+(f64 islands, unfused mul/add, shared libm recipe) the GPU result is expected to
+be BIT-IDENTICAL to the oracle's; the tests assert that, and the RMSE bound as
+the stated tolerance."""
+import numpy as np
+import pytest
+
+from yuki_amd import abi, scenes
+
+pytestmark = pytest.mark.gpu
+SEED = 0x73B9642E74AC471C
+TOL_RMSE = 1e-4
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _rmse(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def _render_both(ctx, yk, oracle, sd, res, sampler, integ, tile_dim=16, threads=0):
+    fs = yk.FilmSettings(res=res, tile_dim=tile_dim)
+    cam = yk.Camera(sd.camera, fs)
+    tiles = yk.film_tiles(fs)
+    sc = yk.Scene(ctx, sd)
+    it = yk.IntegratorType.instantiate(ctx, integ)
+    got, stats = it.render_tiles(sc, cam, sampler, tiles)
+    osc = oracle.OracleScene(sd)
+    want, rays = osc.render_tiles(cam.matrices, sampler, integ, tiles, n_threads=threads)
+    return got, stats, want, rays
+
+
+CASES = [
+    ("cornell-tris", (96, 96), "uniform", 8),
+    ("cornell-tris", (64, 48), "stratified", 8),
+    ("city-tiny", (128, 72), "stratified", 8),
+    ("city-small", (160, 90), "uniform", 8),
+    ("city-small", (96, 54), "stratified", 16),
+    ("cfg2", (160, 90), "uniform", 8),
+]
+
+
+@pytest.mark.parametrize("name,res,skind,depth", CASES)
+def test_path_render_matches_oracle(ctx, yk, oracle, name, res, skind, depth):
+    sd = scenes.by_name(name)
+    sampler = yk.SamplerType.Uniform(8, SEED) if skind == "uniform" else yk.SamplerType.Stratified((3, 3), True, SEED)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=depth))
+    got, stats, want, rays = _render_both(ctx, yk, oracle, sd, res, sampler, integ)
+    assert stats.rays == rays  # the reference's ray_count (path.rs:87)
+    assert np.isfinite(want).all()
+    assert _rmse(got, want) < TOL_RMSE
+    mism = int((_bits(got) != _bits(want)).sum())
+    assert mism == 0, f"{mism} of {got.size} channel values differ from the oracle bit pattern"
+
+
+def test_indirect_clamp(ctx, yk, oracle):
+    sd = scenes.by_name("city-tiny")
+    sampler = yk.SamplerType.Uniform(4, SEED)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=6, indirect_clamp=0.25))
+    got, stats, want, rays = _render_both(ctx, yk, oracle, sd, (96, 54), sampler, integ)
+    assert stats.rays == rays
+    assert np.array_equal(_bits(got), _bits(want))
+
+
+@pytest.mark.parametrize("integ_name", ["GeometryNormals", "ShadingNormals", "BVHIntersections"])
+def test_debug_integrators(ctx, yk, oracle, integ_name):
+    sd = scenes.by_name("city-small")
+    sampler = yk.SamplerType.Uniform(2, SEED)
+    integ = getattr(yk.IntegratorType, integ_name)
+    got, stats, want, rays = _render_both(ctx, yk, oracle, sd, (128, 72), sampler, integ)
+    assert stats.rays == rays == 128 * 72 * 2
+    assert np.array_equal(_bits(got), _bits(want))
+
+
+def test_single_tile_is_the_trait_method(ctx, yk, oracle):
+    """Integrator::render(tile) == the same pixels of a whole-film render; ragged
+    edge tile (film.rs:306-309 clips tiles to the film)."""
+    sd = scenes.by_name("city-tiny")
+    fs = yk.FilmSettings(res=(70, 41), tile_dim=16)
+    cam = yk.Camera(sd.camera, fs)
+    sc = yk.Scene(ctx, sd)
+    sampler = yk.SamplerType.Stratified((2, 2), True, SEED)
+    it = yk.IntegratorType.instantiate(ctx, yk.IntegratorType.Path(yk.PathParams(max_depth=5)))
+    tiles = yk.film_tiles(fs)
+    whole, stats = it.render_tiles(sc, cam, sampler, tiles)
+    film = yk.update_tiles(tiles, whole, fs.res)
+    osc = oracle.OracleScene(sd)
+    total = 0
+    for t in [tiles[0], tiles[-1], tiles[len(tiles) // 2]]:
+        px, rays = it.render(sc, cam, sampler, yk.FilmTile(bb=(t["x0"], t["y0"], t["x1"], t["y1"])))
+        h, w = int(t["y1"]) - int(t["y0"]), int(t["x1"]) - int(t["x0"])
+        assert np.array_equal(_bits(px.reshape(h, w, 3)), _bits(film[t["y0"] : t["y1"], t["x0"] : t["x1"]]))
+        want, orays = osc.render_tiles(cam.matrices, sampler, it.desc, np.array([t]), n_threads=1)
+        assert rays == orays
+        assert np.array_equal(_bits(px), _bits(want))
+        total += rays
+    assert total > 0
+
+
+def test_result_independent_of_batch_size(yk, oracle):
+    """Paths are independent: cutting the work into different batches (and thus
+    different compaction orders) must not change a single bit."""
+    sd = scenes.by_name("city-tiny")
+    fs = yk.FilmSettings(res=(64, 36))
+    sampler = yk.SamplerType.Uniform(4, SEED)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=8))
+    outs = []
+    for batch in (1 << 20, 4096, 777):
+        c = yk.Context(0, batch_paths=batch)
+        sc = yk.Scene(c, sd)
+        cam = yk.Camera(sd.camera, fs)
+        out, st = yk.IntegratorType.instantiate(c, integ).render_tiles(sc, cam, sampler, yk.film_tiles(fs))
+        outs.append((out, st.rays))
+        sc.close()
+        c.close()
+    for o, r in outs[1:]:
+        assert r == outs[0][1]
+        assert np.array_equal(_bits(o), _bits(outs[0][0]))
+
+
+def test_li_matches_render(ctx, yk, oracle):
+    """Integrator::li on caller-supplied camera rays == what render computes for them."""
+    sd = scenes.by_name("city-tiny")
+    fs = yk.FilmSettings(res=(32, 32), tile_dim=32)
+    cam = yk.Camera(sd.camera, fs)
+    sc = yk.Scene(ctx, sd)
+    for sampler in (yk.SamplerType.Uniform(1, SEED), yk.SamplerType.Stratified((1, 1), True, SEED)):
+        it = yk.IntegratorType.instantiate(ctx, yk.IntegratorType.Path(yk.PathParams(max_depth=6)))
+        tile = (0, 0, 32, 32)
+        px, _ = it.render(sc, cam, sampler, yk.FilmTile(bb=tile))
+        o, d = yk.camera_rays(ctx, cam, sampler, tile, 0)
+        xy = np.stack(np.meshgrid(np.arange(32), np.arange(32), indexing="xy"), axis=-1).reshape(-1, 2).astype(np.uint16)
+        li = it.li(sc, sampler, o, d, xy, np.zeros(len(o), dtype=np.uint32), dimension=2)
+        assert np.array_equal(_bits(li), _bits(px))
+
+
+def test_error_behaviour(ctx, yk):
+    """Contract violations the reference asserts on come back as status codes."""
+    sd = scenes.by_name("city-tiny")
+    sc = yk.Scene(ctx, sd)
+    cam = yk.Camera(sd.camera, yk.FilmSettings(res=(32, 32)))
+    it = yk.IntegratorType.instantiate(ctx, yk.IntegratorType.Path(yk.PathParams(max_depth=2)))
+    with pytest.raises(yk.YukiError) as e:
+        it.render(sc, cam, yk.SamplerType.Uniform(1), yk.FilmTile(bb=(8, 8, 8, 16)))  # Bounds2 with a dimension <= 0
+    assert e.value.status == 1
+    with pytest.raises(yk.YukiError) as e:
+        yk.IntegratorType.instantiate(ctx, yk.IntegratorType.Whitted(3)).render(sc, cam, yk.SamplerType.Uniform(1), yk.FilmTile(bb=(0, 0, 8, 8)))
+    assert e.value.status == 5
+    with pytest.raises(yk.YukiError) as e:
+        yk.Scene(ctx, scenes.cornell())  # the sphere has no device kernel yet
+    assert e.value.status == 5
+    # cancellation: the predicate is polled before every batch
+    with pytest.raises(yk.YukiError) as e:
+        it.render_tiles(sc, cam, yk.SamplerType.Uniform(1), yk.film_tiles(yk.FilmSettings(res=(32, 32))), cancel=lambda: True)
+    assert e.value.status == 7

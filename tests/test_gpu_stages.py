@@ -1,0 +1,180 @@
+"""GPU parity, stage by stage: every kernel-level building block of the wavefront
+against the CPU oracle on the same seeded inputs.  Bit-exact unless stated."""
+import numpy as np
+import pytest
+
+from yuki_amd import abi, scenes
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x73B9642E74AC471C
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_device_libm_matches_oracle_bit_exact(ctx, yk, oracle):
+    rng = np.random.default_rng(1)
+    L = oracle.lib()
+    x = np.concatenate([rng.uniform(-7, 7, 200000), rng.uniform(-1e4, 1e4, 20000), [0.0, -0.0, 1e-30, 3.1415927, 1.5707964]]).astype(np.float32)
+    for fn, name in [(0, "orc_sinf"), (1, "orc_cosf"), (2, "orc_tanf")]:
+        got = yk.device_math(ctx, fn, x)
+        want = np.array([getattr(L, name)(float(v)) for v in x[:20000]], dtype=np.float32)
+        assert np.array_equal(_bits(got[:20000]), _bits(want)), name
+    pos = np.abs(x[:20000]) + np.float32(1e-6)
+    assert np.array_equal(_bits(yk.device_math(ctx, 3, pos)), _bits(np.array([L.orc_logf(float(v)) for v in pos], dtype=np.float32)))
+    c = rng.uniform(-1, 1, 20000).astype(np.float32)
+    assert np.array_equal(_bits(yk.device_math(ctx, 4, c)), _bits(np.array([L.orc_acosf(float(v)) for v in c], dtype=np.float32)))
+    y = rng.uniform(-3, 3, 20000).astype(np.float32)
+    got = yk.device_math(ctx, 5, y, x[:20000])
+    want = np.array([L.orc_atan2f(float(a), float(b)) for a, b in zip(y, x[:20000])], dtype=np.float32)
+    assert np.array_equal(_bits(got), _bits(want))
+
+
+def test_device_sqrt_div_are_correctly_rounded(ctx, yk):
+    """f32 sqrt and division on gfx950 must equal IEEE (numpy) results: the
+    reference's f32::sqrt and `/` are correctly rounded."""
+    rng = np.random.default_rng(2)
+    a = np.concatenate([rng.uniform(0, 1e6, 300000), rng.uniform(0, 1e-30, 1000), 10.0 ** rng.uniform(-38, 38, 100000)]).astype(np.float32)
+    b = np.concatenate([rng.uniform(-1e3, 1e3, 300000), rng.uniform(1e-20, 1e-10, 1000), 10.0 ** rng.uniform(-30, 30, 100000)]).astype(np.float32)
+    assert np.array_equal(_bits(yk.device_math(ctx, 6, a)), _bits(np.sqrt(a)))
+    assert np.array_equal(_bits(yk.device_math(ctx, 8, a)), _bits(np.sqrt(a.astype(np.float64)).astype(np.float32)))
+    with np.errstate(all="ignore"):
+        assert np.array_equal(_bits(yk.device_math(ctx, 7, a, b)), _bits(a / b))
+
+
+@pytest.mark.parametrize("kind", ["uniform", "stratified", "stratified_nojitter"])
+def test_sampler_sequence(ctx, yk, oracle, kind):
+    if kind == "uniform":
+        s = yk.SamplerType.Uniform(16, SEED)
+    else:
+        s = yk.SamplerType.Stratified((8, 8), kind == "stratified", SEED)
+    dims = np.array([2, 2, 2, 2, 1, 2, 2, 1, 1, 2] * 4, dtype=np.uint8)
+    import ctypes as C
+
+    for px, py, idx in [(0, 0, 0), (17, 1033, 5), (1919, 1079, 15), (65535, 65535, 3)]:
+        got = yk.sampler_sequence(ctx, s, px, py, idx, dims)
+        want = np.zeros((len(dims), 2), dtype=np.float32)
+        oracle.lib().orc_sampler_sequence(C.byref(s), px, py, idx, dims.ctypes.data_as(C.c_void_p), len(dims), want.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(_bits(got), _bits(want)), (kind, px, py, idx)
+
+
+def test_camera_rays(ctx, yk, oracle):
+    sd = scenes.by_name("cfg2")
+    fs = yk.FilmSettings(res=(1920, 1080))
+    cam = yk.Camera(sd.camera, fs)
+    s = yk.SamplerType.Stratified((4, 4), True, SEED)
+    for tile, idx in [((0, 0, 16, 16), 0), ((1904, 1072, 1920, 1080), 7), ((960, 528, 976, 544), 15)]:
+        o1, d1 = yk.camera_rays(ctx, cam, s, tile, idx)
+        o2, d2 = oracle.camera_rays(cam.matrices, s, tile, idx)
+        assert np.array_equal(_bits(o1), _bits(o2))
+        assert np.array_equal(_bits(d1), _bits(d2))
+
+
+def _random_rays(sd, n, seed):
+    rng = np.random.default_rng(seed)
+    lo, hi = sd.points.min(axis=0), sd.points.max(axis=0)
+    ext = hi - lo
+    o = (lo - 0.3 * ext + rng.uniform(0, 1, (n, 3)) * 1.6 * ext).astype(np.float32)
+    tgt = (lo + rng.uniform(0, 1, (n, 3)) * ext).astype(np.float32)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # a share of axis-aligned and zero-component directions (0*inf NaN lanes in the slab test)
+    k = n // 20
+    d[:k] = 0
+    d[np.arange(k), rng.integers(0, 3, k)] = rng.choice([-1.0, 1.0], k)
+    d[k : 2 * k, rng.integers(0, 3)] = 0
+    return o, d.astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["cornell-tris", "city-small", "cfg2"])
+def test_trace_closest_bit_exact(ctx, yk, oracle, name):
+    sd = scenes.by_name(name)
+    sc = yk.Scene(ctx, sd)
+    osc = oracle.OracleScene(sd)
+    o, d = _random_rays(sd, 60000, 3)
+    got = sc.intersect(o, d, counters=True)
+    want = osc.intersect(o, d)
+    assert np.array_equal(got["shape"], want["shape"])
+    hit = want["shape"] >= 0
+    assert hit.sum() > 1000
+    assert np.array_equal(_bits(got["t"][hit]), _bits(want["t"][hit]))
+    # IntersectionResult counters (bvh.rs:167-179) — the BVHIntersections integrator's output
+    assert np.array_equal(got["node_tests"], want["node_tests"])
+    assert np.array_equal(got["node_hits"], want["node_hits"])
+    assert np.array_equal(got["shape_tests"], want["shape_tests"])
+    # with a finite t_max
+    tm = (np.abs(np.random.default_rng(4).normal(1.0, 0.7, o.shape[0])) + 0.01).astype(np.float32)
+    got = sc.intersect(o, d, t_max=tm)
+    want = osc.intersect(o, d, t_max=tm)
+    assert np.array_equal(got["shape"], want["shape"])
+
+
+@pytest.mark.parametrize("name", ["cornell-tris", "city-small"])
+def test_trace_any_bit_exact(ctx, yk, oracle, name):
+    sd = scenes.by_name(name)
+    sc = yk.Scene(ctx, sd)
+    osc = oracle.OracleScene(sd)
+    o, d = _random_rays(sd, 60000, 5)
+    rng = np.random.default_rng(6)
+    d = (d * rng.uniform(0.2, 3.0, (o.shape[0], 1))).astype(np.float32)  # shadow rays are not normalised
+    tm = np.full(o.shape[0], 0.9999, dtype=np.float32)
+    al = rng.integers(-1, max(1, len(sd.lights)), o.shape[0]).astype(np.int32)
+    got = sc.any_intersect(o, d, tm, al)
+    want = osc.any_intersect(o, d, tm, al)
+    assert np.array_equal(got, want)
+    assert 0.05 < want.mean() < 0.95
+
+
+MATERIALS = [
+    dict(kind=abi.MAT_MATTE, a=(0.7, 0.5, 0.3), c=0.0),
+    dict(kind=abi.MAT_MATTE, a=(0.7, 0.5, 0.3), c=0.349),
+    dict(kind=abi.MAT_MATTE, a=(0, 0, 0), c=0.0),
+    dict(kind=abi.MAT_GLASS, a=(1, 1, 1), b=(0.9, 0.95, 1.0), c=1.5),
+    dict(kind=abi.MAT_METAL, a=(0.27105, 0.67693, 1.31640), b=(3.60920, 2.62480, 2.29210), c=0.01, remap=True),
+    dict(kind=abi.MAT_METAL, a=(0.2, 0.9, 1.1), b=(3.9, 2.4, 2.2), c=0.2, remap=False),
+    dict(kind=abi.MAT_GLOSSY, a=(0.8, 0.6, 0.2), c=0.3, remap=False),
+    dict(kind=abi.MAT_GLOSSY, a=(0.8, 0.6, 0.2), c=0.4, remap=True),
+]
+
+
+def _mat(m):
+    d = abi.MaterialDesc()
+    d.kind = m["kind"]
+    d.a = abi.f3(m.get("a", (0, 0, 0)))
+    d.b = abi.f3(m.get("b", (0, 0, 0)))
+    d.c = m.get("c", 0.0)
+    d.flags = 1 if m.get("remap") else 0
+    return d
+
+
+@pytest.mark.parametrize("mi", range(len(MATERIALS)))
+def test_bsdf_f_and_sample_f_bit_exact(ctx, yk, oracle, mi):
+    import ctypes as C
+
+    m = _mat(MATERIALS[mi])
+    rng = np.random.default_rng(10 + mi)
+    n = 4000
+
+    def unit(k):
+        v = rng.normal(size=(k, 3))
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+    ns = unit(n)
+    ng = (ns + 0.1 * unit(n)).astype(np.float32)
+    ng /= np.linalg.norm(ng, axis=1, keepdims=True)
+    dpdu = np.cross(ns, unit(n)).astype(np.float32)
+    wo, wi = unit(n), unit(n)
+    u = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    got_f = yk.bsdf_eval(ctx, m, ng, ns, dpdu, wo, wi)
+    got_s = yk.bsdf_sample(ctx, m, ng, ns, dpdu, wo, u)
+    want_f = np.zeros((n, 3), dtype=np.float32)
+    want_s = np.zeros((n, 8), dtype=np.float32)
+    L = oracle.lib()
+    p = lambda a, i: a[i : i + 1].ctypes.data_as(C.c_void_p)
+    for i in range(n):
+        L.orc_bsdf_eval(C.byref(m), p(ng, i), p(ns, i), p(dpdu, i), p(wo, i), p(wi, i), p(want_f, i))
+        L.orc_bsdf_sample(C.byref(m), p(ng, i), p(ns, i), p(dpdu, i), p(wo, i), p(u, i), p(want_s, i))
+    assert np.array_equal(_bits(got_f), _bits(want_f))
+    assert np.array_equal(_bits(got_s), _bits(want_s))

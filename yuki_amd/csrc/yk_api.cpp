@@ -1,0 +1,1099 @@
+// yk_api.cpp — the C ABI (include/yuki_hip.h): context, scene upload, and the
+// batch scheduler that drives the wavefront kernels.
+//
+// The scheduler plays the role of the reference's RenderManager/RenderWorker
+// pair (renderer/render_manager.rs:69-193, render_worker.rs:62-137): instead of
+// num_cpus-1 threads popping 16x16 tiles, ALL pixels x samples of the submitted
+// tiles become one work range that is cut into batches of `batch_paths` camera
+// samples; each batch runs raygen + max_depth x (trace, shade, shadow,
+// accumulate) without any host synchronisation — queue lengths live in device
+// memory and the persistent kernels read them there.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "yk_device.h"
+#include "yk_host.h"
+#include "yk_kernels.h"
+
+using namespace yk;
+
+// ------------------------------------------------------------------ helpers
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t want) {
+        if (want <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct yk_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    int n_cu = 256;
+    // options
+    int64_t batch_paths = 4 << 20;
+    int64_t sample_buf_cap = (int64_t)64 << 30;
+    int64_t time_kernels = 1;
+    // work buffers
+    DevBuf path[2][4];
+    DevBuf hit, pend, shO, shD, shC, vis, shq, ctrl, spill, sample_buf, pixel_xy, tiles, tile_off, counters, stats4, hit4, scratch[8];
+    size_t cap_paths = 0;
+    unsigned cap_lights = 0;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+struct yk_scene {
+    yk_context* ctx = nullptr;
+    HostBvh bvh;
+    uint32_t n_triangles = 0, n_spheres = 0, n_lights = 0;
+    yk_scene_info info;
+    // device
+    DevBuf nodes, tris, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights;
+    DevScene dev;
+    bool on_device = false;
+};
+
+static yk_status fail(yk_context* ctx, yk_status st, const std::string& msg) {
+    if (ctx) ctx->last_error = msg;
+    return st;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                           \
+    do {                                                                                                             \
+        hipError_t _e = (expr);                                                                                      \
+        if (_e != hipSuccess) {                                                                                      \
+            return fail(ctx, _e == hipErrorOutOfMemory ? YK_ERR_OUT_OF_MEMORY : YK_ERR_DEVICE,                       \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                                          \
+        }                                                                                                            \
+    } while (0)
+
+static double now_seconds() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <class T> static yk_status upload(yk_context* ctx, DevBuf& buf, const T* src, size_t count) {
+    size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    HIP_TRY(ctx, buf.ensure(bytes));
+    if (count) HIP_TRY(ctx, hipMemcpy(buf.p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return YK_OK;
+}
+
+extern "C" {
+
+uint32_t yk_abi_version(void) { return YK_ABI_VERSION; }
+
+const char* yk_status_string(yk_status s) {
+    switch (s) {
+        case YK_OK: return "ok";
+        case YK_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case YK_ERR_NO_DEVICE: return "no HIP device";
+        case YK_ERR_DEVICE: return "HIP error";
+        case YK_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case YK_ERR_UNSUPPORTED: return "unsupported on the device path";
+        case YK_ERR_BVH_BUILD: return "BVH build failed";
+        case YK_ERR_CANCELLED: return "cancelled";
+        case YK_ERR_STACK_OVERFLOW: return "traversal stack overflow";
+    }
+    return "unknown";
+}
+
+yk_status yk_context_create(int device, yk_context** out) {
+    if (!out) return YK_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return YK_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return YK_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(device) != hipSuccess) return YK_ERR_NO_DEVICE;
+    yk_context* ctx = new yk_context();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return YK_ERR_DEVICE;
+    }
+    *out = ctx;
+    return YK_OK;
+}
+
+void yk_context_destroy(yk_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 4; ++b) ctx->path[a][b].release();
+    DevBuf* all[] = {&ctx->hit, &ctx->pend, &ctx->shO, &ctx->shD, &ctx->shC, &ctx->vis, &ctx->shq, &ctx->ctrl, &ctx->spill, &ctx->sample_buf,
+                     &ctx->pixel_xy, &ctx->tiles, &ctx->tile_off, &ctx->counters, &ctx->stats4, &ctx->hit4};
+    for (DevBuf* b : all) b->release();
+    for (DevBuf& b : ctx->scratch) b.release();
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+yk_status yk_last_error(const yk_context* ctx, char* buf, size_t cap) {
+    if (!ctx || !buf || cap == 0) return YK_ERR_INVALID_ARGUMENT;
+    std::snprintf(buf, cap, "%s", ctx->last_error.c_str());
+    return YK_OK;
+}
+
+yk_status yk_context_set_option(yk_context* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return YK_ERR_INVALID_ARGUMENT;
+    std::string k(key);
+    if (k == "batch_paths") {
+        if (value < 64 || value > ((int64_t)1 << 30)) return YK_ERR_INVALID_ARGUMENT;
+        ctx->batch_paths = value;
+    } else if (k == "sample_buf_cap") {
+        if (value < (1 << 20)) return YK_ERR_INVALID_ARGUMENT;
+        ctx->sample_buf_cap = value;
+    } else if (k == "time_kernels") {
+        ctx->time_kernels = value;
+    } else {
+        return YK_ERR_INVALID_ARGUMENT;
+    }
+    return YK_OK;
+}
+
+// ------------------------------------------------------------------ host helpers
+yk_status yk_camera_init(const yk_camera_params* params, yk_camera* out) { return camera_init(params, out); }
+
+size_t yk_film_tiles(uint16_t res_x, uint16_t res_y, uint16_t tile_dim, yk_tile* out, size_t cap) {
+    std::vector<yk_tile> t = film_tiles(res_x, res_y, tile_dim);
+    if (out)
+        for (size_t i = 0; i < t.size() && i < cap; ++i) out[i] = t[i];
+    return t.size();
+}
+
+yk_status yk_make_rect_light(const float l2w[16], const float l2w_inv[16], const float radiance[3], const float size[2], yk_light_desc* out) {
+    if (!l2w || !l2w_inv || !radiance || !size || !out) return YK_ERR_INVALID_ARGUMENT;
+    std::memset(out, 0, sizeof(*out));
+    Xf light_to_world = xf_from(l2w, l2w_inv);
+    Xf sample_to_light = xf_mul(xf_scale(size[0], 1.0f, size[1]), xf_translation(-0.5f, 0.0f, -0.5f));
+    Xf sample_to_world = xf_mul(light_to_world, sample_to_light);
+    out->kind = YK_LIGHT_RECT;
+    for (int k = 0; k < 3; ++k) out->i[k] = radiance[k];
+    std::memcpy(out->sample_to_world, sample_to_world.m, 64);
+    std::memcpy(out->sample_to_world_inv, sample_to_world.mi, 64);
+    out->area = size[0] * size[1];
+    return YK_OK;
+}
+
+yk_status yk_make_spot_light(const float l2w[16], const float l2w_inv[16], const float intensity[3], float total_width_degrees,
+                             float falloff_start_degrees, yk_light_desc* out) {
+    if (!l2w || !l2w_inv || !intensity || !out) return YK_ERR_INVALID_ARGUMENT;
+    std::memset(out, 0, sizeof(*out));
+    V3 p = xf_point(l2w, V3{0.0f, 0.0f, 0.0f});
+    out->kind = YK_LIGHT_SPOT;
+    out->p[0] = p.x;
+    out->p[1] = p.y;
+    out->p[2] = p.z;
+    for (int k = 0; k < 3; ++k) out->i[k] = intensity[k];
+    out->cos_total_width = det_cosf(total_width_degrees * (YK_PI / 180.0f));
+    out->cos_falloff_start = det_cosf(falloff_start_degrees * (YK_PI / 180.0f));
+    std::memcpy(out->world_to_light, l2w_inv, 64);
+    return YK_OK;
+}
+
+yk_status yk_make_point_light(const float l2w[16], const float intensity[3], yk_light_desc* out) {
+    if (!l2w || !intensity || !out) return YK_ERR_INVALID_ARGUMENT;
+    std::memset(out, 0, sizeof(*out));
+    V3 p = xf_point(l2w, V3{0.0f, 0.0f, 0.0f});
+    out->kind = YK_LIGHT_POINT;
+    out->p[0] = p.x;
+    out->p[1] = p.y;
+    out->p[2] = p.z;
+    for (int k = 0; k < 3; ++k) out->i[k] = intensity[k];
+    return YK_OK;
+}
+
+yk_status yk_film_update_tiles(const yk_tile* tiles, size_t n_tiles, const float* tile_rgb, uint16_t res_x, uint16_t res_y, float* film_rgb) {
+    if (!tiles || !tile_rgb || !film_rgb) return YK_ERR_INVALID_ARGUMENT;
+    size_t off = 0;
+    for (size_t t = 0; t < n_tiles; ++t) {
+        const yk_tile& tl = tiles[t];
+        if (tl.x1 > res_x || tl.y1 > res_y || tl.x0 >= tl.x1 || tl.y0 >= tl.y1) return YK_ERR_INVALID_ARGUMENT;  // film.rs:227-234
+        size_t w = (size_t)tl.x1 - tl.x0;
+        for (size_t y = tl.y0; y < tl.y1; ++y) {
+            std::memcpy(film_rgb + 3 * (y * res_x + tl.x0), tile_rgb + 3 * off, 3 * w * sizeof(float));
+            off += w;
+        }
+    }
+    return YK_OK;
+}
+
+// ------------------------------------------------------------------ scene
+static Material make_material(const yk_material_desc& m) {
+    Material r;
+    std::memset(&r, 0, sizeof(r));
+    for (int k = 0; k < 3; ++k) {
+        r.a[k] = m.a[k];
+        r.b[k] = m.b[k];
+    }
+    const bool remap = (m.flags & 1u) != 0;
+    switch (m.kind) {
+        case YK_MAT_MATTE: {  // matte.rs:27-39
+            if (m.a[0] == 0.0f && m.a[1] == 0.0f && m.a[2] == 0.0f) {
+                r.kind = MK_BLACK;
+            } else if (m.c == 0.0f) {
+                r.kind = MK_LAMBERT;
+            } else {  // oren_nayar.rs:20-27
+                r.kind = MK_OREN_NAYAR;
+                float sigma2 = m.c * m.c;
+                r.c = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
+                r.d = 0.45f * sigma2 / (sigma2 + 0.09f);
+            }
+            break;
+        }
+        case YK_MAT_GLASS:
+            r.kind = MK_GLASS;
+            r.c = m.c;
+            break;
+        case YK_MAT_METAL: {  // metal.rs:39-50, trowbridge_reitz.rs:15-20
+            r.kind = MK_METAL;
+            float roughness = remap ? roughness_to_alpha(m.c) : m.c;
+            r.c = rmax(roughness, 0.001f);
+            break;
+        }
+        default: {  // glossy.rs:37-49
+            r.kind = MK_GLOSSY;
+            float roughness = remap ? roughness_to_alpha(m.c) : m.c;
+            r.c = rmax(roughness * roughness, 0.001f);
+            break;
+        }
+    }
+    return r;
+}
+
+static DevLight make_light(const yk_light_desc& l) {
+    DevLight d;
+    std::memset(&d, 0, sizeof(d));
+    d.kind = l.kind;
+    for (int k = 0; k < 3; ++k) {
+        d.p[k] = l.p[k];
+        d.i[k] = l.i[k];
+    }
+    d.cos_total_width = l.cos_total_width;
+    d.cos_falloff_start = l.cos_falloff_start;
+    std::memcpy(d.w2l, l.world_to_light, 64);
+    std::memcpy(d.s2w, l.sample_to_world, 64);
+    V3 n = xf_normal(l.sample_to_world_inv, V3{0.0f, -1.0f, 0.0f});  // rectangular_light.rs:48
+    d.n[0] = n.x;
+    d.n[1] = n.y;
+    d.n[2] = n.z;
+    d.area = l.area;
+    return d;
+}
+
+yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** out) {
+    if (!d || !out) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null scene description");
+    *out = nullptr;
+    if ((uint64_t)d->n_triangles + d->n_spheres == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "empty scene");
+    if (d->n_triangles && (!d->points || !d->indices)) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "missing geometry arrays");
+    if (d->max_shapes_in_node == 0 || d->max_shapes_in_node > 65535u || d->split_method > 2) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "bad BVH settings");
+    for (uint32_t i = 0; i < d->n_triangles; ++i) {
+        for (int k = 0; k < 3; ++k)
+            if (d->indices[3 * i + k] >= d->n_vertices) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "vertex index out of range");
+        if (d->tri_mesh && d->tri_mesh[i] >= d->n_meshes) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "mesh index out of range");
+        if (d->tri_material && (d->tri_material[i] < 0 || (uint32_t)d->tri_material[i] >= d->n_materials))
+            return fail(ctx, YK_ERR_INVALID_ARGUMENT, "material index out of range");
+        if (d->tri_area_light && d->tri_area_light[i] >= (int32_t)d->n_lights) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "light index out of range");
+    }
+    if (d->n_triangles && (!d->tri_material || d->n_materials == 0 || d->n_meshes == 0))
+        return fail(ctx, YK_ERR_INVALID_ARGUMENT, "triangles need materials and meshes");
+    for (uint32_t m = 0; m < d->n_meshes; ++m) {
+        if (d->meshes[m].has_normals && !d->normals) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "mesh has_normals without a normals array");
+        if (d->meshes[m].has_uvs && !d->uvs) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "mesh has_uvs without a uvs array");
+    }
+    if (ctx && d->n_spheres) return fail(ctx, YK_ERR_UNSUPPORTED, "spheres are not implemented on the device path");
+
+    yk_scene* s = new yk_scene();
+    s->ctx = ctx;
+    s->n_triangles = d->n_triangles;
+    s->n_spheres = d->n_spheres;
+    s->n_lights = d->n_lights;
+    std::memset(&s->info, 0, sizeof(s->info));
+
+    // world bounds of every shape: Triangle::world_bound (triangle.rs:229-235),
+    // Sphere::world_bound (sphere.rs:121-123)
+    std::vector<ShapeBounds> sb((size_t)d->n_triangles + d->n_spheres);
+    for (uint32_t i = 0; i < d->n_triangles; ++i) {
+        const float* p0 = d->points + 3 * (size_t)d->indices[3 * i];
+        const float* p1 = d->points + 3 * (size_t)d->indices[3 * i + 1];
+        const float* p2 = d->points + 3 * (size_t)d->indices[3 * i + 2];
+        for (int k = 0; k < 3; ++k) {
+            sb[i].bmin[k] = rmin(rmin(p0[k], p1[k]), p2[k]);
+            sb[i].bmax[k] = rmax(rmax(p0[k], p1[k]), p2[k]);
+        }
+    }
+    for (uint32_t i = 0; i < d->n_spheres; ++i) {
+        const yk_sphere_desc& sp = d->spheres[i];
+        const float r = sp.radius;
+        const float lo[3] = {-r, -r, -r}, hi[3] = {r, r, r};
+        const float big = 3.40282347e+38f;
+        ShapeBounds b = {{big, big, big}, {-big, -big, -big}};
+        const int corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};  // transform.rs:194-206
+        for (int c = 0; c < 8; ++c) {
+            V3 q = xf_point(sp.object_to_world, V3{corner[c][0] ? hi[0] : lo[0], corner[c][1] ? hi[1] : lo[1], corner[c][2] ? hi[2] : lo[2]});
+            const float qq[3] = {q.x, q.y, q.z};
+            for (int k = 0; k < 3; ++k) {
+                b.bmin[k] = rmin(b.bmin[k], qq[k]);
+                b.bmax[k] = rmax(b.bmax[k], qq[k]);
+            }
+        }
+        sb[(size_t)d->n_triangles + i] = b;
+    }
+    double t0 = now_seconds();
+    build_bvh(sb, d->max_shapes_in_node, d->split_method, s->bvh);
+    s->info.build_seconds = now_seconds() - t0;
+    if (s->bvh.split_failed || s->bvh.nodes.empty()) {
+        delete s;
+        return fail(ctx, YK_ERR_BVH_BUILD, "BVH split failed (reference: assert_ne!(mid, start))");
+    }
+    s->info.n_nodes = s->bvh.nodes.size();
+    s->info.n_shapes = s->bvh.shape_order.size();
+    s->info.max_leaf_shapes = s->bvh.max_leaf_shapes;
+    s->info.tree_depth = s->bvh.depth;
+    for (int k = 0; k < 3; ++k) {
+        s->info.bounds_min[k] = s->bvh.nodes[0].bmin[k];
+        s->info.bounds_max[k] = s->bvh.nodes[0].bmax[k];
+    }
+    uint64_t n_interior = 0;
+    for (const yk_bvh_node& n : s->bvh.nodes) n_interior += n.is_leaf ? 0 : 1;
+    s->info.n_interior = n_interior;
+
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        double u0 = now_seconds();
+        const std::vector<yk_bvh_node>& nodes = s->bvh.nodes;
+        // interior index of each reference node = number of interior nodes before it
+        std::vector<uint32_t> interior_index(nodes.size());
+        uint32_t cnt = 0;
+        for (size_t i = 0; i < nodes.size(); ++i) {
+            interior_index[i] = cnt;
+            if (!nodes[i].is_leaf) ++cnt;
+        }
+        auto ref_of = [&](uint32_t idx) -> uint32_t { return nodes[idx].is_leaf ? (YK_LEAF_BIT | nodes[idx].a) : interior_index[idx]; };
+        std::vector<DevNode> dn(std::max<size_t>(n_interior, 1));
+        for (size_t i = 0; i < nodes.size(); ++i) {
+            if (nodes[i].is_leaf) continue;
+            const yk_bvh_node& c0 = nodes[i + 1];
+            const yk_bvh_node& c1 = nodes[nodes[i].a];
+            DevNode& o = dn[interior_index[i]];
+            o.q0 = make_float4(c0.bmin[0], c0.bmin[1], c0.bmin[2], c0.bmax[0]);
+            o.q1 = make_float4(c0.bmax[1], c0.bmax[2], c1.bmin[0], c1.bmin[1]);
+            o.q2 = make_float4(c1.bmin[2], c1.bmax[0], c1.bmax[1], c1.bmax[2]);
+            o.q3 = make_uint4(ref_of((uint32_t)i + 1), ref_of(nodes[i].a), nodes[i].axis, 0u);
+        }
+        const size_t np = s->bvh.shape_order.size();
+        std::vector<float4> tris(3 * np);
+        std::vector<uint8_t> last(np, 0);
+        for (const yk_bvh_node& n : nodes)
+            if (n.is_leaf) last[(size_t)n.a + n.count - 1] = 1;
+        for (size_t p = 0; p < np; ++p) {
+            uint32_t src = s->bvh.shape_order[p];
+            const float* p0 = d->points + 3 * (size_t)d->indices[3 * src];
+            const float* p1 = d->points + 3 * (size_t)d->indices[3 * src + 1];
+            const float* p2 = d->points + 3 * (size_t)d->indices[3 * src + 2];
+            int al = d->tri_area_light ? d->tri_area_light[src] : -1;
+            uint32_t alb = (uint32_t)al, lastb = last[p];
+            float w0, w1, w2;
+            std::memcpy(&w0, &alb, 4);
+            std::memcpy(&w1, &src, 4);
+            std::memcpy(&w2, &lastb, 4);
+            tris[3 * p + 0] = make_float4(p0[0], p0[1], p0[2], w0);
+            tris[3 * p + 1] = make_float4(p1[0], p1[1], p1[2], w1);
+            tris[3 * p + 2] = make_float4(p2[0], p2[1], p2[2], w2);
+        }
+        std::vector<uint32_t> mesh_flags(std::max<uint32_t>(d->n_meshes, 1), 0);
+        for (uint32_t m = 0; m < d->n_meshes; ++m)
+            mesh_flags[m] = (d->meshes[m].has_normals ? YK_MESH_NORMALS : 0u) | (d->meshes[m].has_uvs ? YK_MESH_UVS : 0u) |
+                            (d->meshes[m].swaps_handedness ? YK_MESH_SWAPS : 0u);
+        std::vector<Material> mats(std::max<uint32_t>(d->n_materials, 1));
+        for (uint32_t m = 0; m < d->n_materials; ++m) mats[m] = make_material(d->materials[m]);
+        std::vector<DevLight> lights(std::max<uint32_t>(d->n_lights, 1));
+        for (uint32_t l = 0; l < d->n_lights; ++l) lights[l] = make_light(d->lights[l]);
+        std::vector<uint32_t> tri_mesh(d->n_triangles, 0);
+        if (d->tri_mesh) std::memcpy(tri_mesh.data(), d->tri_mesh, sizeof(uint32_t) * d->n_triangles);
+        std::vector<int32_t> tri_al(d->n_triangles, -1);
+        if (d->tri_area_light) std::memcpy(tri_al.data(), d->tri_area_light, sizeof(int32_t) * d->n_triangles);
+
+        yk_status st;
+#define UP(buf, ptr, n)                                   \
+    if ((st = upload(ctx, s->buf, ptr, n)) != YK_OK) {    \
+        yk_scene_destroy(s);                              \
+        return st;                                        \
+    }
+        UP(nodes, dn.data(), dn.size());
+        UP(tris, tris.data(), tris.size());
+        UP(indices, d->indices, 3 * (size_t)d->n_triangles);
+        UP(points, d->points, 3 * (size_t)d->n_vertices);
+        UP(normals, d->normals, d->normals ? 3 * (size_t)d->n_vertices : 0);
+        UP(uvs, d->uvs, d->uvs ? 2 * (size_t)d->n_vertices : 0);
+        UP(tri_mesh, tri_mesh.data(), tri_mesh.size());
+        UP(tri_material, d->tri_material, (size_t)d->n_triangles);
+        UP(tri_area_light, tri_al.data(), tri_al.size());
+        UP(mesh_flags, mesh_flags.data(), mesh_flags.size());
+        UP(materials, mats.data(), mats.size());
+        UP(lights, lights.data(), lights.size());
+#undef UP
+        DevScene& ds = s->dev;
+        ds.nodes = s->nodes.as<DevNode>();
+        ds.tris = s->tris.as<float4>();
+        ds.root_ref = ref_of(0);
+        for (int k = 0; k < 3; ++k) {
+            ds.root_bmin[k] = nodes[0].bmin[k];
+            ds.root_bmax[k] = nodes[0].bmax[k];
+            ds.background[k] = d->background[k];
+        }
+        ds.indices = s->indices.as<uint32_t>();
+        ds.points = s->points.as<float>();
+        ds.normals = s->normals.as<float>();
+        ds.uvs = s->uvs.as<float>();
+        ds.tri_mesh = s->tri_mesh.as<uint32_t>();
+        ds.tri_material = s->tri_material.as<int32_t>();
+        ds.tri_area_light = s->tri_area_light.as<int32_t>();
+        ds.mesh_flags = s->mesh_flags.as<uint32_t>();
+        ds.materials = s->materials.as<Material>();
+        ds.lights = s->lights.as<DevLight>();
+        ds.n_lights = d->n_lights;
+        s->on_device = true;
+        s->info.upload_seconds = now_seconds() - u0;
+        DevBuf* all[] = {&s->nodes, &s->tris, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
+                         &s->mesh_flags, &s->materials, &s->lights};
+        for (DevBuf* b : all) s->info.device_bytes += b->bytes;
+    }
+    *out = s;
+    return YK_OK;
+}
+
+void yk_scene_destroy(yk_scene* s) {
+    if (!s) return;
+    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    DevBuf* all[] = {&s->nodes, &s->tris, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
+                     &s->mesh_flags, &s->materials, &s->lights};
+    for (DevBuf* b : all) b->release();
+    delete s;
+}
+
+yk_status yk_scene_get_info(const yk_scene* s, yk_scene_info* out) {
+    if (!s || !out) return YK_ERR_INVALID_ARGUMENT;
+    *out = s->info;
+    return YK_OK;
+}
+
+yk_status yk_scene_export_bvh(const yk_scene* s, yk_bvh_node* nodes, uint32_t* shape_order) {
+    if (!s) return YK_ERR_INVALID_ARGUMENT;
+    if (nodes) std::memcpy(nodes, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(yk_bvh_node));
+    if (shape_order) std::memcpy(shape_order, s->bvh.shape_order.data(), s->bvh.shape_order.size() * sizeof(uint32_t));
+    return YK_OK;
+}
+
+// ------------------------------------------------------------------ render
+static yk_status ensure_work_buffers(yk_context* ctx, size_t paths, unsigned n_lights) {
+    unsigned nl = std::max(1u, n_lights);
+    if (paths <= ctx->cap_paths && nl <= ctx->cap_lights) return YK_OK;
+    paths = std::max(paths, ctx->cap_paths);
+    nl = std::max(nl, ctx->cap_lights);
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 4; ++b) HIP_TRY(ctx, ctx->path[a][b].ensure(paths * 16));
+    HIP_TRY(ctx, ctx->hit.ensure(paths * 4));
+    HIP_TRY(ctx, ctx->pend.ensure(paths * 16));
+    HIP_TRY(ctx, ctx->shO.ensure(paths * nl * 16));
+    HIP_TRY(ctx, ctx->shD.ensure(paths * nl * 16));
+    HIP_TRY(ctx, ctx->shC.ensure(paths * nl * 16));
+    HIP_TRY(ctx, ctx->vis.ensure(paths * nl));
+    HIP_TRY(ctx, ctx->shq.ensure(paths * nl * 4));
+    HIP_TRY(ctx, ctx->ctrl.ensure(YK_CTRL_WORDS * 4));
+    HIP_TRY(ctx, ctx->counters.ensure(64));
+    ctx->cap_paths = paths;
+    ctx->cap_lights = nl;
+    return YK_OK;
+}
+
+static unsigned trace_grid(const yk_context* ctx) { return (unsigned)ctx->n_cu * 5u; }
+
+static yk_status ensure_spill(yk_context* ctx) {
+    size_t threads = (size_t)trace_grid(ctx) * trace_block_size();
+    HIP_TRY(ctx, ctx->spill.ensure(threads * trace_spill_depth() * 8));
+    return YK_OK;
+}
+
+static PathBuffers path_buffers(yk_context* ctx, int which) {
+    PathBuffers p;
+    p.rayO = ctx->path[which][0].as<float4>();
+    p.rayD = ctx->path[which][1].as<float4>();
+    p.thru = ctx->path[which][2].as<float4>();
+    p.rngs = ctx->path[which][3].as<uint4>();
+    return p;
+}
+
+static yk_status make_params(yk_context* ctx, const yk_sampler_desc* smp, const yk_integrator_desc* integ, RenderParams& prm) {
+    if (!smp || !integ) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null sampler/integrator");
+    std::memset(&prm, 0, sizeof(prm));
+    prm.sampler.kind = smp->kind;
+    prm.sampler.nx = smp->nx;
+    prm.sampler.ny = smp->kind == YK_SAMPLER_UNIFORM ? 1 : smp->ny;
+    prm.sampler.jitter = smp->jitter;
+    prm.sampler.seed = smp->seed;
+    if (smp->kind > 1 || prm.sampler.nx == 0 || prm.sampler.ny == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "bad sampler");
+    uint64_t spp = (uint64_t)prm.sampler.nx * prm.sampler.ny;
+    if (spp > 0xFFFFu) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "samples per pixel exceed u16 (integrators/mod.rs:139)");
+    prm.sampler.spp = (unsigned)spp;
+    prm.max_depth = integ->max_depth;
+    prm.has_clamp = integ->has_clamp;
+    prm.clamp = integ->indirect_clamp;
+    prm.integrator = integ->kind;
+    if (integ->kind == YK_INTEGRATOR_WHITTED) return fail(ctx, YK_ERR_UNSUPPORTED, "Whitted has no device kernel (CPU oracle only)");
+    if (integ->kind > YK_INTEGRATOR_SHADING_NORMALS) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "bad integrator kind");
+    return YK_OK;
+}
+
+struct KernelTimer {
+    yk_context* ctx;
+    bool on;
+    std::vector<std::pair<int, int>> spans[3];  // 0 trace, 1 shadow, 2 shade
+    size_t used = 0;
+    int begin(hipStream_t s) {
+        if (!on) return -1;
+        if (used + 2 > ctx->ev_pool.size()) {
+            size_t old = ctx->ev_pool.size();
+            ctx->ev_pool.resize(old + 256);
+            for (size_t i = old; i < ctx->ev_pool.size(); ++i) (void)hipEventCreate(&ctx->ev_pool[i]);
+        }
+        int a = (int)used;
+        used += 2;
+        (void)hipEventRecord(ctx->ev_pool[a], s);
+        return a;
+    }
+    void end(int a, int cls, hipStream_t s) {
+        if (a < 0) return;
+        (void)hipEventRecord(ctx->ev_pool[a + 1], s);
+        spans[cls].push_back(std::make_pair(a, a + 1));
+    }
+    double total(int cls) {
+        double ms = 0.0;
+        for (auto& sp : spans[cls]) {
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, ctx->ev_pool[sp.first], ctx->ev_pool[sp.second]) == hipSuccess) ms += t;
+        }
+        return ms * 1e-3;
+    }
+};
+
+// one batch of `n` paths already generated into buffer 0; runs the bounce loop
+static void run_bounces(yk_context* ctx, hipStream_t st, const yk_scene* scene, const RenderParams& prm, const uint32_t* pixel_xy,
+                        const uint32_t* sample_index_tab, float4* sample_buf, KernelTimer& kt, unsigned long long* counters) {
+    unsigned* ctrl = ctx->ctrl.as<unsigned>();
+    const DevScene& ds = scene->dev;
+    const unsigned tg = trace_grid(ctx);
+    const unsigned sg = (unsigned)ctx->n_cu * 8u;
+    unsigned cur = 0;
+    for (unsigned b = 0; b < prm.max_depth; ++b) {
+        PathBuffers pc = path_buffers(ctx, (int)cur), pn = path_buffers(ctx, (int)(cur ^ 1u));
+        // reset the consumer-side counters of this bounce
+        (void)hipMemsetAsync(ctrl + (cur ^ 1u), 0, 4, st);
+        (void)hipMemsetAsync(ctrl + YK_CTRL_SHQ, 0, 4, st);
+        int e = kt.begin(st);
+        launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, ctrl + cur, ctrl + YK_CTRL_HEADS + 2 * b, ctx->hit.as<int>(), nullptr, nullptr,
+                             ctx->spill.as<uint2>(), tg * trace_block_size(), ctrl, counters);
+        kt.end(e, 0, st);
+        e = kt.begin(st);
+        launch_shade(st, sg, ds, prm, pixel_xy, sample_index_tab, pc, pn, ctx->hit.as<int>(), ctx->pend.as<float4>(), ctx->shO.as<float4>(),
+                     ctx->shD.as<float4>(), ctx->shC.as<float4>(), ctx->vis.as<unsigned char>(), ctx->shq.as<unsigned>(), ctrl, cur);
+        kt.end(e, 2, st);
+        e = kt.begin(st);
+        launch_trace_any(st, tg, ds, ctx->shO.as<float4>(), ctx->shD.as<float4>(), ctx->shq.as<unsigned>(), ctrl + YK_CTRL_SHQ,
+                         ctrl + YK_CTRL_HEADS + 2 * b + 1, ctx->vis.as<unsigned char>(), ctx->spill.as<uint2>(), tg * trace_block_size(), ctrl,
+                         counters + 1);
+        kt.end(e, 1, st);
+        launch_accumulate(st, sg, prm, pc, ctx->pend.as<float4>(), ctx->shC.as<float4>(), ctx->vis.as<unsigned char>(), ds.n_lights, sample_buf, ctrl, cur);
+        cur ^= 1u;
+    }
+}
+
+yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                 const yk_integrator_desc* integrator, const yk_tile* tiles, size_t n_tiles, void* d_out_rgb, void* stream,
+                                 yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!scene || !camera || !tiles || n_tiles == 0 || !d_out_rgb) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
+    if (!scene->on_device || scene->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context");
+    RenderParams prm;
+    yk_status ps = make_params(ctx, sampler, integrator, prm);
+    if (ps != YK_OK) return ps;
+    if (prm.integrator == YK_INTEGRATOR_PATH && prm.max_depth > (YK_CTRL_WORDS - YK_CTRL_HEADS) / 2)
+        return fail(ctx, YK_ERR_INVALID_ARGUMENT, "max_depth too large");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+
+    // tiles -> pixel ranges (assert!(tile_pixels.len() >= tile.bb.area()), integrators/mod.rs:131)
+    std::vector<uint32_t> off(n_tiles + 1, 0);
+    uint64_t total_px = 0;
+    for (size_t t = 0; t < n_tiles; ++t) {
+        if (tiles[t].x0 >= tiles[t].x1 || tiles[t].y0 >= tiles[t].y1) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "Bounds2 with a dimension <= 0");
+        total_px += (uint64_t)(tiles[t].x1 - tiles[t].x0) * (uint64_t)(tiles[t].y1 - tiles[t].y0);
+        if (total_px > 0xFFFFFFFFull) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many pixels in one call");
+        off[t + 1] = (uint32_t)total_px;
+    }
+    const uint32_t spp = prm.sampler.spp;
+    // chunk so that sample ids fit u32 and the sample buffer stays under the cap
+    uint64_t max_px_chunk = std::min<uint64_t>(0xFFFFFFF0ull / spp, (uint64_t)ctx->sample_buf_cap / (16ull * spp));
+    if (max_px_chunk == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "sample_buf_cap too small for one pixel");
+
+    DevCamera cam;
+    std::memcpy(cam.c2w, camera->camera_to_world, 64);
+    std::memcpy(cam.r2c, camera->raster_to_camera, 64);
+
+    const bool is_path = prm.integrator == YK_INTEGRATOR_PATH;
+    size_t batch = (size_t)std::min<uint64_t>((uint64_t)ctx->batch_paths, total_px * spp);
+    yk_status wb = ensure_work_buffers(ctx, batch, scene->n_lights);
+    if (wb != YK_OK) return wb;
+    if ((wb = ensure_spill(ctx)) != YK_OK) return wb;
+    HIP_TRY(ctx, ctx->tiles.ensure(n_tiles * sizeof(yk_tile)));
+    HIP_TRY(ctx, ctx->tile_off.ensure((n_tiles + 1) * 4));
+    if (!is_path && prm.integrator == YK_INTEGRATOR_BVH_INTERSECTIONS) HIP_TRY(ctx, ctx->stats4.ensure(batch * 16));
+
+    unsigned long long* counters = ctx->counters.as<unsigned long long>();
+    HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64, st));
+    KernelTimer kt;
+    kt.ctx = ctx;
+    kt.on = stats != nullptr && ctx->time_kernels != 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (stats) {
+        HIP_TRY(ctx, hipEventCreate(&ev0));
+        HIP_TRY(ctx, hipEventCreate(&ev1));
+        HIP_TRY(ctx, hipEventRecord(ev0, st));
+    }
+    uint32_t n_batches = 0, n_trace = 0;
+    unsigned* ctrl = ctx->ctrl.as<unsigned>();
+    float* out = reinterpret_cast<float*>(d_out_rgb);
+
+    size_t t_begin = 0;
+    while (t_begin < n_tiles) {
+        size_t t_end = t_begin;
+        while (t_end < n_tiles && (uint64_t)(off[t_end + 1] - off[t_begin]) <= max_px_chunk) ++t_end;
+        if (t_end == t_begin) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "a single tile exceeds sample_buf_cap");
+        const uint32_t px0 = off[t_begin], npx = off[t_end] - off[t_begin];
+        std::vector<uint32_t> loc(t_end - t_begin + 1);
+        for (size_t t = t_begin; t <= t_end; ++t) loc[t - t_begin] = off[t] - px0;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->tiles.p, tiles + t_begin, (t_end - t_begin) * sizeof(yk_tile), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->tile_off.p, loc.data(), loc.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));  // `loc` is a stack-lifetime staging buffer
+        HIP_TRY(ctx, ctx->pixel_xy.ensure((size_t)npx * 4));
+        HIP_TRY(ctx, ctx->sample_buf.ensure((size_t)npx * spp * 16));
+        uint32_t* pixel_xy = ctx->pixel_xy.as<uint32_t>();
+        float4* sample_buf = ctx->sample_buf.as<float4>();
+        launch_pixel_table(st, ctx->tiles.as<yk_tile>(), ctx->tile_off.as<uint32_t>(), (uint32_t)(t_end - t_begin), npx, pixel_xy);
+
+        const uint64_t work = (uint64_t)npx * spp;
+        for (uint64_t w0 = 0; w0 < work; w0 += batch) {
+            if (cancel && cancel(user)) {
+                (void)hipStreamSynchronize(st);
+                if (ev0) (void)hipEventDestroy(ev0);
+                if (ev1) (void)hipEventDestroy(ev1);
+                return fail(ctx, YK_ERR_CANCELLED, "cancelled by early_termination_predicate");
+            }
+            const uint32_t n = (uint32_t)std::min<uint64_t>(batch, work - w0);
+            HIP_TRY(ctx, hipMemsetAsync(ctrl, 0, YK_CTRL_WORDS * 4, st));
+            launch_raygen(st, cam, prm, pixel_xy, w0, n, path_buffers(ctx, 0), sample_buf, ctrl);
+            ++n_batches;
+            if (is_path) {
+                run_bounces(ctx, st, scene, prm, pixel_xy, nullptr, sample_buf, kt, counters);
+                n_trace += prm.max_depth;
+            } else {
+                PathBuffers pc = path_buffers(ctx, 0);
+                const bool want_stats = prm.integrator == YK_INTEGRATOR_BVH_INTERSECTIONS;
+                int e = kt.begin(st);
+                launch_trace_closest(st, trace_grid(ctx), scene->dev, pc.rayO, pc.rayD, nullptr, ctrl, ctrl + YK_CTRL_HEADS, ctx->hit.as<int>(), nullptr,
+                                     want_stats ? ctx->stats4.as<uint4>() : nullptr, ctx->spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), ctrl,
+                                     counters);
+                kt.end(e, 0, st);
+                launch_debug_shade(st, scene->dev, prm.integrator, pc, ctx->hit.as<int>(), ctx->stats4.as<uint4>(), n, sample_buf);
+                ++n_trace;
+            }
+        }
+        launch_resolve(st, sample_buf, npx, spp, out + 3 * (size_t)px0);
+        t_begin = t_end;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    if (stats) {
+        HIP_TRY(ctx, hipEventRecord(ev1, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        std::memset(stats, 0, sizeof(*stats));
+        unsigned long long host_counters[8];
+        unsigned host_ctrl[4];
+        HIP_TRY(ctx, hipMemcpy(host_counters, counters, 64, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(host_ctrl, ctrl, 16, hipMemcpyDeviceToHost));
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, ev0, ev1);
+        stats->rays = host_counters[0];
+        stats->shadow_rays = host_counters[1];
+        stats->samples = total_px * spp;
+        stats->seconds_total = ms * 1e-3;
+        stats->seconds_trace = kt.total(0);
+        stats->seconds_shadow = kt.total(1);
+        stats->seconds_shade = kt.total(2);
+        stats->trace_launches = n_trace;
+        stats->batches = n_batches;
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+        if (host_ctrl[YK_CTRL_ERR] & 1u) return fail(ctx, YK_ERR_STACK_OVERFLOW, "BVH traversal stack exceeded 64 entries (bvh.rs:174)");
+    }
+    return YK_OK;
+}
+
+yk_status yk_render_tiles(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                          const yk_integrator_desc* integrator, const yk_tile* tiles, size_t n_tiles, float* out_rgb, yk_render_stats* stats,
+                          yk_cancel_fn cancel, void* user) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!tiles || n_tiles == 0 || !out_rgb) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
+    uint64_t total_px = 0;
+    for (size_t t = 0; t < n_tiles; ++t) {
+        if (tiles[t].x0 >= tiles[t].x1 || tiles[t].y0 >= tiles[t].y1) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "Bounds2 with a dimension <= 0");
+        total_px += (uint64_t)(tiles[t].x1 - tiles[t].x0) * (uint64_t)(tiles[t].y1 - tiles[t].y0);
+    }
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, ctx->scratch[0].ensure(total_px * 12));
+    yk_render_stats local;
+    yk_status st = yk_render_tiles_device(ctx, scene, camera, sampler, integrator, tiles, n_tiles, ctx->scratch[0].p, nullptr, stats ? stats : &local,
+                                          cancel, user);
+    if (st != YK_OK) return st;
+    HIP_TRY(ctx, hipMemcpy(out_rgb, ctx->scratch[0].p, total_px * 12, hipMemcpyDeviceToHost));
+    return YK_OK;
+}
+
+yk_status yk_render_tile(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                         const yk_integrator_desc* integrator, const yk_tile* tile, float* tile_pixels, uint64_t* out_rays) {
+    yk_render_stats stats;
+    yk_status st = yk_render_tiles(ctx, scene, camera, sampler, integrator, tile, 1, tile_pixels, &stats, nullptr, nullptr);
+    if (st == YK_OK && out_rays) *out_rays = stats.rays;
+    return st;
+}
+
+yk_status yk_film_update_tiles_device(yk_context* ctx, const yk_tile* tiles, size_t n_tiles, const void* d_tile_rgb, uint16_t res_x, uint16_t res_y,
+                                      void* d_film_rgb, void* stream) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!tiles || !d_tile_rgb || !d_film_rgb || n_tiles == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    std::vector<uint32_t> off(n_tiles + 1, 0);
+    uint64_t total = 0;
+    for (size_t t = 0; t < n_tiles; ++t) {
+        if (tiles[t].x1 > res_x || tiles[t].y1 > res_y || tiles[t].x0 >= tiles[t].x1 || tiles[t].y0 >= tiles[t].y1)
+            return fail(ctx, YK_ERR_INVALID_ARGUMENT, "update_tile: Tile doesn't fit film");
+        total += (uint64_t)(tiles[t].x1 - tiles[t].x0) * (uint64_t)(tiles[t].y1 - tiles[t].y0);
+        if (total > 0xFFFFFFFFull) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many pixels");
+        off[t + 1] = (uint32_t)total;
+    }
+    HIP_TRY(ctx, ctx->scratch[1].ensure(n_tiles * sizeof(yk_tile)));
+    HIP_TRY(ctx, ctx->scratch[2].ensure((n_tiles + 1) * 4));
+    HIP_TRY(ctx, ctx->scratch[3].ensure(total * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[1].p, tiles, n_tiles * sizeof(yk_tile), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[2].p, off.data(), off.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    launch_pixel_table(st, ctx->scratch[1].as<yk_tile>(), ctx->scratch[2].as<uint32_t>(), (uint32_t)n_tiles, (uint32_t)total, ctx->scratch[3].as<uint32_t>());
+    launch_film_scatter(st, ctx->scratch[3].as<uint32_t>(), (uint32_t)total, reinterpret_cast<const float*>(d_tile_rgb), res_x,
+                        reinterpret_cast<float*>(d_film_rgb));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return YK_OK;
+}
+
+yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* sampler, const yk_integrator_desc* integrator, size_t n,
+                const float* ray_o, const float* ray_d, const uint16_t* pixel_xy, const uint32_t* sample_index, uint32_t dimension, float* out_li,
+                uint32_t* out_ray_counts) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!scene || !ray_o || !ray_d || !pixel_xy || !sample_index || !out_li || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
+    if (!scene->on_device || scene->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context");
+    if (n > ((size_t)1 << 28)) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many rays");
+    RenderParams prm;
+    yk_status ps = make_params(ctx, sampler, integrator, prm);
+    if (ps != YK_OK) return ps;
+    if (prm.integrator != YK_INTEGRATOR_PATH) return fail(ctx, YK_ERR_UNSUPPORTED, "yk_li implements the Path integrator");
+    if (prm.max_depth > (YK_CTRL_WORDS - YK_CTRL_HEADS) / 2) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "max_depth too large");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    yk_status wb = ensure_work_buffers(ctx, n, scene->n_lights);
+    if (wb != YK_OK) return wb;
+    if ((wb = ensure_spill(ctx)) != YK_OK) return wb;
+    HIP_TRY(ctx, ctx->scratch[4].ensure(n * 12));
+    HIP_TRY(ctx, ctx->scratch[5].ensure(n * 12));
+    HIP_TRY(ctx, ctx->scratch[6].ensure(n * 4));
+    HIP_TRY(ctx, ctx->scratch[7].ensure(n * 4));
+    HIP_TRY(ctx, ctx->pixel_xy.ensure(n * 4));
+    HIP_TRY(ctx, ctx->sample_buf.ensure(n * 16));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[4].p, ray_o, n * 12, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[5].p, ray_d, n * 12, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[6].p, pixel_xy, n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[7].p, sample_index, n * 4, hipMemcpyHostToDevice, st));
+    unsigned* ctrl = ctx->ctrl.as<unsigned>();
+    unsigned long long* counters = ctx->counters.as<unsigned long long>();
+    HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64, st));
+    HIP_TRY(ctx, hipMemsetAsync(ctrl, 0, YK_CTRL_WORDS * 4, st));
+    launch_raygen_user(st, prm, ctx->scratch[4].as<float>(), ctx->scratch[5].as<float>(), ctx->scratch[6].as<uint16_t>(), ctx->scratch[7].as<uint32_t>(),
+                       dimension, (uint32_t)n, path_buffers(ctx, 0), ctx->sample_buf.as<float4>(), ctx->pixel_xy.as<uint32_t>(), ctrl);
+    KernelTimer kt;
+    kt.ctx = ctx;
+    kt.on = false;
+    run_bounces(ctx, st, scene, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), ctx->sample_buf.as<float4>(), kt, counters);
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<float> tmp(n * 4);
+    HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->sample_buf.p, n * 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (size_t i = 0; i < n; ++i) {
+        out_li[3 * i] = tmp[4 * i];
+        out_li[3 * i + 1] = tmp[4 * i + 1];
+        out_li[3 * i + 2] = tmp[4 * i + 2];
+    }
+    if (out_ray_counts) std::memset(out_ray_counts, 0, n * 4);  // per-ray counts are not tracked by the wavefront
+    return YK_OK;
+}
+
+// ------------------------------------------------------------------ per-stage entry points
+yk_status yk_trace_closest(yk_context* ctx, const yk_scene* scene, size_t n, const float* ray_o, const float* ray_d, const float* t_max,
+                           int32_t* out_shape, float* out_t, float* out_bary, uint32_t* out_node_tests, uint32_t* out_node_hits,
+                           uint32_t* out_shape_tests) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!scene || !ray_o || !ray_d || !out_shape || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
+    if (!scene->on_device || scene->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context");
+    if (n > 0xFFFFFF00ull) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many rays");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    yk_status wb = ensure_work_buffers(ctx, n, scene->n_lights);
+    if (wb != YK_OK) return wb;
+    if ((wb = ensure_spill(ctx)) != YK_OK) return wb;
+    const bool want_stats = out_node_tests || out_node_hits || out_shape_tests;
+    HIP_TRY(ctx, ctx->scratch[4].ensure(n * 12));
+    HIP_TRY(ctx, ctx->scratch[5].ensure(n * 12));
+    HIP_TRY(ctx, ctx->scratch[6].ensure(n * 4));
+    HIP_TRY(ctx, ctx->hit4.ensure(n * 16));
+    if (want_stats) HIP_TRY(ctx, ctx->stats4.ensure(n * 16));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[4].p, ray_o, n * 12, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[5].p, ray_d, n * 12, hipMemcpyHostToDevice, st));
+    if (t_max) HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[6].p, t_max, n * 4, hipMemcpyHostToDevice, st));
+    PathBuffers pb = path_buffers(ctx, 0);
+    launch_pack_rays(st, n, ctx->scratch[4].as<float>(), ctx->scratch[5].as<float>(), pb.rayO, pb.rayD);
+    unsigned* ctrl = ctx->ctrl.as<unsigned>();
+    HIP_TRY(ctx, hipMemsetAsync(ctrl, 0, YK_CTRL_WORDS * 4, st));
+    unsigned nn = (unsigned)n;
+    HIP_TRY(ctx, hipMemcpyAsync(ctrl, &nn, 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    launch_trace_closest(st, trace_grid(ctx), scene->dev, pb.rayO, pb.rayD, t_max ? ctx->scratch[6].as<float>() : nullptr, ctrl, ctrl + YK_CTRL_HEADS,
+                         ctx->hit.as<int>(), ctx->hit4.as<float4>(), want_stats ? ctx->stats4.as<uint4>() : nullptr, ctx->spill.as<uint2>(),
+                         trace_grid(ctx) * trace_block_size(), ctrl, nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out_shape, ctx->hit.p, n * 4, hipMemcpyDeviceToHost, st));
+    std::vector<float> h4;
+    if (out_t || out_bary) {
+        h4.resize(n * 4);
+        HIP_TRY(ctx, hipMemcpyAsync(h4.data(), ctx->hit4.p, n * 16, hipMemcpyDeviceToHost, st));
+    }
+    std::vector<uint32_t> s4;
+    if (want_stats) {
+        s4.resize(n * 4);
+        HIP_TRY(ctx, hipMemcpyAsync(s4.data(), ctx->stats4.p, n * 16, hipMemcpyDeviceToHost, st));
+    }
+    unsigned host_ctrl[4];
+    HIP_TRY(ctx, hipMemcpyAsync(host_ctrl, ctrl, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (size_t i = 0; i < n; ++i) {
+        if (out_t) out_t[i] = out_shape[i] >= 0 ? h4[4 * i] : __builtin_inff();
+        if (out_bary) {
+            out_bary[3 * i] = out_shape[i] >= 0 ? h4[4 * i + 1] : 0.0f;
+            out_bary[3 * i + 1] = out_shape[i] >= 0 ? h4[4 * i + 2] : 0.0f;
+            out_bary[3 * i + 2] = out_shape[i] >= 0 ? h4[4 * i + 3] : 0.0f;
+        }
+        if (out_node_tests) out_node_tests[i] = s4[4 * i];
+        if (out_node_hits) out_node_hits[i] = s4[4 * i + 1];
+        if (out_shape_tests) out_shape_tests[i] = s4[4 * i + 2];
+    }
+    if (host_ctrl[YK_CTRL_ERR] & 1u) return fail(ctx, YK_ERR_STACK_OVERFLOW, "BVH traversal stack exceeded 64 entries (bvh.rs:174)");
+    return YK_OK;
+}
+
+yk_status yk_trace_any(yk_context* ctx, const yk_scene* scene, size_t n, const float* ray_o, const float* ray_d, const float* t_max,
+                       const int32_t* area_light, uint8_t* out_hit) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!scene || !ray_o || !ray_d || !t_max || !out_hit || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
+    if (!scene->on_device || scene->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context");
+    if (n > 0xFFFFFF00ull) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many rays");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    yk_status wb = ensure_work_buffers(ctx, n, scene->n_lights);
+    if (wb != YK_OK) return wb;
+    if ((wb = ensure_spill(ctx)) != YK_OK) return wb;
+    HIP_TRY(ctx, ctx->scratch[4].ensure(n * 12));
+    HIP_TRY(ctx, ctx->scratch[5].ensure(n * 12));
+    HIP_TRY(ctx, ctx->scratch[6].ensure(n * 4));
+    HIP_TRY(ctx, ctx->scratch[7].ensure(n * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[4].p, ray_o, n * 12, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[5].p, ray_d, n * 12, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[6].p, t_max, n * 4, hipMemcpyHostToDevice, st));
+    if (area_light) HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[7].p, area_light, n * 4, hipMemcpyHostToDevice, st));
+    launch_pack_shadow_rays(st, n, ctx->scratch[4].as<float>(), ctx->scratch[5].as<float>(), ctx->scratch[6].as<float>(),
+                            area_light ? ctx->scratch[7].as<int>() : nullptr, ctx->shO.as<float4>(), ctx->shD.as<float4>());
+    unsigned* ctrl = ctx->ctrl.as<unsigned>();
+    HIP_TRY(ctx, hipMemsetAsync(ctrl, 0, YK_CTRL_WORDS * 4, st));
+    unsigned nn = (unsigned)n;
+    HIP_TRY(ctx, hipMemcpyAsync(ctrl, &nn, 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    launch_trace_any(st, trace_grid(ctx), scene->dev, ctx->shO.as<float4>(), ctx->shD.as<float4>(), nullptr, ctrl, ctrl + YK_CTRL_HEADS,
+                     ctx->vis.as<unsigned char>(), ctx->spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), ctrl, nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out_hit, ctx->vis.p, n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return YK_OK;
+}
+
+yk_status yk_sampler_sequence(yk_context* ctx, const yk_sampler_desc* sampler, uint16_t px, uint16_t py, uint32_t sample_index, const uint8_t* dims,
+                              size_t n_draws, float* out) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!sampler || !dims || !out || n_draws == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
+    RenderParams prm;
+    yk_integrator_desc dummy = {YK_INTEGRATOR_PATH, 1, 0, 0.0f};
+    yk_status ps = make_params(ctx, sampler, &dummy, prm);
+    if (ps != YK_OK) return ps;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, ctx->scratch[4].ensure(n_draws));
+    HIP_TRY(ctx, ctx->scratch[5].ensure(n_draws * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[4].p, dims, n_draws, hipMemcpyHostToDevice, st));
+    launch_sampler_sequence(st, prm.sampler, px, py, sample_index, ctx->scratch[4].as<uint8_t>(), n_draws, ctx->scratch[5].as<float>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->scratch[5].p, n_draws * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return YK_OK;
+}
+
+yk_status yk_camera_rays(yk_context* ctx, const yk_camera* camera, const yk_sampler_desc* sampler, const yk_tile* tile, uint32_t sample_index,
+                         float* out_o, float* out_d) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!camera || !sampler || !tile || !out_o || !out_d) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
+    if (tile->x0 >= tile->x1 || tile->y0 >= tile->y1) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "Bounds2 with a dimension <= 0");
+    RenderParams prm;
+    yk_integrator_desc dummy = {YK_INTEGRATOR_PATH, 1, 0, 0.0f};
+    yk_status ps = make_params(ctx, sampler, &dummy, prm);
+    if (ps != YK_OK) return ps;
+    if (sample_index >= prm.sampler.spp) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "sample_index >= samples per pixel");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    const uint32_t npx = (uint32_t)(tile->x1 - tile->x0) * (uint32_t)(tile->y1 - tile->y0);
+    const uint32_t spp = prm.sampler.spp;
+    yk_status wb = ensure_work_buffers(ctx, (size_t)npx * spp, 1);
+    if (wb != YK_OK) return wb;
+    uint32_t off[2] = {0, npx};
+    HIP_TRY(ctx, ctx->tiles.ensure(sizeof(yk_tile)));
+    HIP_TRY(ctx, ctx->tile_off.ensure(8));
+    HIP_TRY(ctx, ctx->pixel_xy.ensure((size_t)npx * 4));
+    HIP_TRY(ctx, ctx->sample_buf.ensure((size_t)npx * spp * 16));
+    HIP_TRY(ctx, ctx->scratch[4].ensure((size_t)npx * spp * 12));
+    HIP_TRY(ctx, ctx->scratch[5].ensure((size_t)npx * spp * 12));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->tiles.p, tile, sizeof(yk_tile), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->tile_off.p, off, 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    launch_pixel_table(st, ctx->tiles.as<yk_tile>(), ctx->tile_off.as<uint32_t>(), 1, npx, ctx->pixel_xy.as<uint32_t>());
+    DevCamera cam;
+    std::memcpy(cam.c2w, camera->camera_to_world, 64);
+    std::memcpy(cam.r2c, camera->raster_to_camera, 64);
+    PathBuffers pb = path_buffers(ctx, 0);
+    launch_raygen(st, cam, prm, ctx->pixel_xy.as<uint32_t>(), 0, npx * spp, pb, ctx->sample_buf.as<float4>(), ctx->ctrl.as<unsigned>());
+    launch_unpack_rays(st, (size_t)npx * spp, pb.rayO, pb.rayD, ctx->scratch[4].as<float>(), ctx->scratch[5].as<float>());
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<float> o((size_t)npx * spp * 3), d((size_t)npx * spp * 3);
+    HIP_TRY(ctx, hipMemcpyAsync(o.data(), ctx->scratch[4].p, o.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d.data(), ctx->scratch[5].p, d.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (uint32_t p = 0; p < npx; ++p)
+        for (int k = 0; k < 3; ++k) {
+            out_o[3 * p + k] = o[3 * ((size_t)p * spp + sample_index) + k];
+            out_d[3 * p + k] = d[3 * ((size_t)p * spp + sample_index) + k];
+        }
+    return YK_OK;
+}
+
+yk_status yk_device_math(yk_context* ctx, int fn, size_t n, const float* a, const float* b, float* out) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!a || !out || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, ctx->scratch[4].ensure(n * 4));
+    HIP_TRY(ctx, ctx->scratch[5].ensure(n * 4));
+    HIP_TRY(ctx, ctx->scratch[6].ensure(n * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[4].p, a, n * 4, hipMemcpyHostToDevice, st));
+    if (b) HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[5].p, b, n * 4, hipMemcpyHostToDevice, st));
+    launch_device_math(st, fn, n, ctx->scratch[4].as<float>(), b ? ctx->scratch[5].as<float>() : nullptr, ctx->scratch[6].as<float>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->scratch[6].p, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return YK_OK;
+}
+
+static yk_status bsdf_common(yk_context* ctx, const yk_material_desc* material, size_t n, const float* n_geom, const float* n_shading,
+                             const float* dpdu, const float* wo, const float* x, int sample, float* out) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!material || !n_geom || !n_shading || !dpdu || !wo || !x || !out || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    const float* src[5] = {n_geom, n_shading, dpdu, wo, x};
+    size_t each[5] = {3, 3, 3, 3, (size_t)(sample ? 2 : 3)};
+    for (int k = 0; k < 5; ++k) {
+        HIP_TRY(ctx, ctx->scratch[k].ensure(n * each[k] * 4));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[k].p, src[k], n * each[k] * 4, hipMemcpyHostToDevice, st));
+    }
+    const size_t out_each = sample ? 8 : 3;
+    HIP_TRY(ctx, ctx->scratch[5].ensure(n * out_each * 4));
+    launch_bsdf_test(st, make_material(*material), n, ctx->scratch[0].as<float>(), ctx->scratch[1].as<float>(), ctx->scratch[2].as<float>(),
+                     ctx->scratch[3].as<float>(), ctx->scratch[4].as<float>(), sample, ctx->scratch[5].as<float>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->scratch[5].p, n * out_each * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return YK_OK;
+}
+
+yk_status yk_bsdf_eval(yk_context* ctx, const yk_material_desc* material, size_t n, const float* n_geom, const float* n_shading, const float* dpdu,
+                       const float* wo, const float* wi, float* out_f) {
+    return bsdf_common(ctx, material, n, n_geom, n_shading, dpdu, wo, wi, 0, out_f);
+}
+yk_status yk_bsdf_sample(yk_context* ctx, const yk_material_desc* material, size_t n, const float* n_geom, const float* n_shading, const float* dpdu,
+                         const float* wo, const float* u, float* out8) {
+    return bsdf_common(ctx, material, n, n_geom, n_shading, dpdu, wo, u, 1, out8);
+}
+
+size_t yk_sizeof(int what) {
+    switch (what) {
+        case 0: return sizeof(yk_scene_desc);
+        case 1: return sizeof(yk_material_desc);
+        case 2: return sizeof(yk_light_desc);
+        case 3: return sizeof(yk_sphere_desc);
+        case 4: return sizeof(yk_camera);
+        case 5: return sizeof(yk_camera_params);
+        case 6: return sizeof(yk_sampler_desc);
+        case 7: return sizeof(yk_integrator_desc);
+        case 8: return sizeof(yk_tile);
+        case 9: return sizeof(yk_bvh_node);
+        case 10: return sizeof(yk_mesh_desc);
+        case 11: return sizeof(yk_render_stats);
+        case 12: return sizeof(yk_scene_info);
+        default: return 0;
+    }
+}
+
+}  // extern "C"

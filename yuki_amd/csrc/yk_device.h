@@ -1,0 +1,108 @@
+// yk_device.h — device-resident data layout of the wavefront Path integrator.
+//
+// HBM layout (all 16-byte records so every lane moves one dwordx4 and a wave one
+// contiguous KiB; "SoA of float4"):
+//
+//   path state, ping-pong (compacted every bounce by `shade`):
+//     rayO[i] = (o.x, o.y, o.z, bits(flags))        flags: bounces | specular<<8
+//     rayD[i] = (d.x, d.y, d.z, bits(sample_id))    sample_id = index into sample_buf
+//     thru[i] = (beta.r, beta.g, beta.b, bits(sampler dimension))
+//     rngs[i] = (state.lo, state.hi, inc.lo, inc.hi)          PCG32 stream of the pixel
+//   per bounce, not carried:
+//     hit[i]                       source triangle or -1             (trace -> shade)
+//     pend[i] = (rgb, bits(kind))  emission / background term        (shade -> accumulate)
+//     shO/shD/shC[i*n_lights+l]    NEE shadow ray + its contribution (shade -> shadow -> accumulate)
+//     vis[i*n_lights+l]            0 none, 1 pending/visible, 2 occluded
+//     shq[k]                       compacted list of pending shadow slots
+//   per chunk:
+//     sample_buf[sample_id] = (L.r, L.g, L.b, -)    radiance of one camera sample
+//     pixel_xy[pixel]       = x | y<<16             pixel of each chunk-local pixel index
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/yuki_hip.h"
+#include "yk_bsdf.h"
+#include "yk_rng.h"
+
+namespace yk {
+
+// BVH interior node, 64 B: both children's AABBs (exact f32 copies of the
+// reference's 32-byte nodes' bounds, bvh.rs:536-556) + child references.
+//   q0 = (c0.min.xyz, c0.max.x) q1 = (c0.max.yz, c1.min.xy) q2 = (c1.min.z, c1.max.xyz)
+//   q3 = (ref0, ref1, split_axis, 0); ref: bit31 set -> leaf, low bits = first primitive
+//                                          else index of an interior node
+struct DevNode {
+    float4 q0, q1, q2;
+    uint4 q3;
+};
+static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
+
+#define YK_LEAF_BIT 0x80000000u
+
+// Light record (lights/*.rs).  n of a rectangular light is constant
+// (sample_to_world * Normal(0,-1,0), rectangular_light.rs:48) and precomputed.
+struct DevLight {
+    uint32_t kind;
+    float p[3];
+    float i[3];
+    float cos_total_width, cos_falloff_start;
+    float w2l[16];  // spot: world_to_light.m
+    float s2w[16];  // rect: sample_to_world.m
+    float n[3];     // rect: transformed normal
+    float area;
+};
+
+// mesh flag bits
+#define YK_MESH_NORMALS 1u
+#define YK_MESH_UVS 2u
+#define YK_MESH_SWAPS 4u
+
+struct DevScene {
+    const DevNode* nodes;
+    const float4* tris;  // 3 per primitive in leaf order: (p0, bits(area_light)) (p1, bits(src_tri)) (p2, bits(last_in_leaf))
+    uint32_t root_ref;
+    float root_bmin[3], root_bmax[3];
+    // shading data, indexed by source triangle
+    const uint32_t* indices;
+    const float* points;
+    const float* normals;
+    const float* uvs;
+    const uint32_t* tri_mesh;
+    const int32_t* tri_material;
+    const int32_t* tri_area_light;
+    const uint32_t* mesh_flags;
+    const Material* materials;
+    const DevLight* lights;
+    uint32_t n_lights;
+    float background[3];
+};
+
+struct DevCamera {
+    float c2w[16];  // camera_to_world.m
+    float r2c[16];  // raster_to_camera.m
+};
+
+struct PathBuffers {
+    float4* rayO;
+    float4* rayD;
+    float4* thru;
+    uint4* rngs;
+};
+
+// control block, zeroed per batch: [0..1] active counts (ping-pong), [2] shadow queue
+// length, [3] error flags, [8+k] work-queue heads of the k-th launch of the batch
+#define YK_CTRL_WORDS 256
+#define YK_CTRL_SHQ 2
+#define YK_CTRL_ERR 3
+#define YK_CTRL_HEADS 8
+
+struct RenderParams {
+    SamplerCfg sampler;
+    uint32_t max_depth;
+    uint32_t has_clamp;
+    float clamp;
+    uint32_t integrator;  // yk_integrator_kind
+};
+
+}  // namespace yk

@@ -1,0 +1,221 @@
+// yk_geom.h — device geometry: slab test, watertight triangle test, surface
+// interaction reconstruction, light sampling.
+#pragma once
+#include "yk_device.h"
+
+namespace yk {
+
+// Per-ray constants of the watertight test (triangle.rs:59-78 recomputes them per
+// triangle; they depend on the ray only, so the values are identical).
+struct RayTri {
+    int kx, ky, kz;
+    float sx, sy, sz;
+};
+YK_HD RayTri ray_tri_setup(V3 d) {
+    RayTri r;
+    r.kz = max_dimension(vabs(d));
+    r.kx = r.kz < 2 ? r.kz + 1 : 0;
+    r.ky = r.kx < 2 ? r.kx + 1 : 0;
+    float dx = comp(d, r.kx), dy = comp(d, r.ky), dz = comp(d, r.kz);
+    r.sx = -dx / dz;
+    r.sy = -dy / dz;
+    r.sz = 1.0f / dz;
+    return r;
+}
+
+struct TriHit {
+    float t, b0, b1, b2;
+};
+
+// Triangle::intersect up to the barycentrics, shapes/triangle.rs:49-139
+YK_HD bool tri_intersect(V3 o, const RayTri& rt, float t_max, V3 p0, V3 p1, V3 p2, TriHit& h) {
+    V3 a = p0 - o, b = p1 - o, c = p2 - o;
+    V3 p0t = V3{comp(a, rt.kx), comp(a, rt.ky), comp(a, rt.kz)};
+    V3 p1t = V3{comp(b, rt.kx), comp(b, rt.ky), comp(b, rt.kz)};
+    V3 p2t = V3{comp(c, rt.kx), comp(c, rt.ky), comp(c, rt.kz)};
+    p0t.x = p0t.x + rt.sx * p0t.z;
+    p0t.y = p0t.y + rt.sy * p0t.z;
+    p1t.x = p1t.x + rt.sx * p1t.z;
+    p1t.y = p1t.y + rt.sy * p1t.z;
+    p2t.x = p2t.x + rt.sx * p2t.z;
+    p2t.y = p2t.y + rt.sy * p2t.z;
+
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {  // f64 fallback, triangle.rs:98-105
+        double e0d = (double)p1t.x * (double)p2t.y - (double)p1t.y * (double)p2t.x;
+        double e1d = (double)p2t.x * (double)p0t.y - (double)p2t.y * (double)p0t.x;
+        double e2d = (double)p0t.x * (double)p1t.y - (double)p0t.y * (double)p1t.x;
+        e0 = (float)e0d;
+        e1 = (float)e1d;
+        e2 = (float)e2d;
+    }
+    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0.0f) return false;
+    float p0z = p0t.z * rt.sz;
+    float p1z = p1t.z * rt.sz;
+    float p2z = p2t.z * rt.sz;
+    float t_scaled = e0 * p0z + e1 * p1z + e2 * p2z;
+    if ((det < 0.0f && (t_scaled >= 0.0f || t_scaled < t_max * det)) || (det > 0.0f && (t_scaled <= 0.0f || t_scaled > t_max * det)))
+        return false;
+    float inv_det = 1.0f / det;
+    h.b0 = e0 * inv_det;
+    h.b1 = e1 * inv_det;
+    h.b2 = e2 * inv_det;
+    h.t = t_scaled * inv_det;
+    return true;
+}
+
+// Bounds3::slab_test + intersect, math/bounds.rs:176-215.  Returns the entry
+// distance through tmin.  The NaN-dropping min/max (0*inf lanes) match Rust's.
+YK_HD bool slab(V3 lo, V3 hi, V3 o, V3 inv, float t_max, float& tmin) {
+    float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
+    float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
+    float nx = fmin_nan(t0x, t1x), ny = fmin_nan(t0y, t1y), nz = fmin_nan(t0z, t1z);
+    float fx = fmax_nan(t0x, t1x), fy = fmax_nan(t0y, t1y), fz = fmax_nan(t0z, t1z);
+    tmin = fmax_nan(fmax_nan(nx, fmax_nan(ny, nz)), 0.0f);
+    float tmax = fmin_nan(fmin_nan(fx, fmin_nan(fy, fz)), t_max);
+    return tmin <= tmax;
+}
+
+// SurfaceInteraction after Triangle::intersect, triangle.rs:141-226 +
+// interaction.rs:95-132 — the fields the integrator reads.
+struct Surface {
+    V3 p;       // si.p
+    V3 n;       // si.n (geometric, face-forwarded to ns when normals exist)
+    V3 ns;      // si.shading.n
+    V3 dpdus;   // si.shading.dpdu
+    int material;
+    int area_light;
+};
+
+YK_HD V3 ld3(const float* a, uint32_t i) { return V3{a[3 * i], a[3 * i + 1], a[3 * i + 2]}; }
+
+YK_HD Surface make_surface(const DevScene& sc, uint32_t tri, const TriHit& h) {
+    uint32_t i0 = sc.indices[3 * tri], i1 = sc.indices[3 * tri + 1], i2 = sc.indices[3 * tri + 2];
+    V3 p0 = ld3(sc.points, i0), p1 = ld3(sc.points, i1), p2 = ld3(sc.points, i2);
+    uint32_t mflags = sc.mesh_flags[sc.tri_mesh[tri]];
+    float u0x = 0.0f, u0y = 0.0f, u1x = 1.0f, u1y = 0.0f, u2x = 1.0f, u2y = 1.0f;  // triangle.rs:143-149
+    if (mflags & YK_MESH_UVS) {
+        u0x = sc.uvs[2 * i0]; u0y = sc.uvs[2 * i0 + 1];
+        u1x = sc.uvs[2 * i1]; u1y = sc.uvs[2 * i1 + 1];
+        u2x = sc.uvs[2 * i2]; u2y = sc.uvs[2 * i2 + 1];
+    }
+    float duv02x = u0x - u2x, duv02y = u0y - u2y;
+    float duv12x = u1x - u2x, duv12y = u1y - u2y;
+    V3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float uv_det = duv02x * duv12y - duv02y * duv12x;
+    V3 dpdu, dpdv;
+    if (uv_det == 0.0f) {
+        V3 nn = normalize(cross(p2 - p0, p1 - p0));
+        coordinate_system(nn, dpdu, dpdv);
+    } else {
+        float inv_uv_det = 1.0f / uv_det;
+        dpdu = (dp02 * duv12y - dp12 * duv02y) * inv_uv_det;
+        dpdv = ((-dp02) * duv12x + dp12 * duv02x) * inv_uv_det;
+    }
+    (void)dpdv;
+    Surface s;
+    s.p = p0 * h.b0 + p1 * h.b1 + p2 * h.b2;
+    V3 n = normalize(cross(dp02, dp12));
+    if (mflags & YK_MESH_SWAPS) n = -n;
+    s.n = n;
+    s.ns = n;
+    s.dpdus = dpdu;
+    if (mflags & YK_MESH_NORMALS) {
+        V3 n0 = ld3(sc.normals, i0), n1 = ld3(sc.normals, i1), n2 = ld3(sc.normals, i2);
+        V3 ns;
+        V3 nn = normalize(n0 * h.b0 + n1 * h.b1 + n2 * h.b2);
+        if (len_sqr(nn) > 0.0f)
+            ns = normalize(nn);  // normalised twice, triangle.rs:203-205
+        else
+            ns = s.n;
+        V3 ss = normalize(dpdu);
+        V3 ts = cross(ss, ns);
+        if (len_sqr(ts) > 0.0f) {
+            ts = normalize(ts);
+            ss = cross(ts, ns);
+        } else {
+            coordinate_system(ns, ss, ts);
+        }
+        // set_shading_geometry, interaction.rs:126-132
+        s.ns = normalize(cross(ss, ts));
+        s.n = faceforward_n(s.n, s.ns);
+        s.dpdus = ss;
+    }
+    s.material = sc.tri_material[tri];
+    s.area_light = sc.tri_area_light[tri];
+    return s;
+}
+
+// Interaction::spawn_ray, interaction.rs:27-40
+YK_HD V3 spawn_origin(V3 p, V3 n, V3 d) {
+    V3 offset = n * 0.001f;
+    return dot(d, n) > 0.0f ? p + offset : p - offset;
+}
+
+struct LightSample {
+    V3 l;
+    RGB li;
+    float pdf;
+    bool has_vis;
+    V3 p1;           // VisibilityTester.p1.p
+    int area_light;  // identity of the sampled area light or -1
+};
+
+// Light::sample_li — point_light.rs:27-50, spot_light.rs:38-80,
+// distant_light.rs:24-43, rectangular_light.rs:46-71
+YK_HD LightSample sample_light(const DevLight& L, int index, V3 sp, float ux, float uy) {
+    LightSample s;
+    s.has_vis = true;
+    s.area_light = -1;
+    s.pdf = 1.0f;
+    V3 lp = V3{L.p[0], L.p[1], L.p[2]};
+    RGB li = RGB{L.i[0], L.i[1], L.i[2]};
+    if (L.kind == YK_LIGHT_POINT) {
+        V3 to_light = lp - sp;
+        float dist_sqr = len_sqr(to_light);
+        s.li = li / dist_sqr;
+        float dist = sqrtf(dist_sqr);
+        s.l = to_light / dist;
+        s.p1 = lp;
+    } else if (L.kind == YK_LIGHT_SPOT) {
+        V3 to_light = lp - sp;
+        float dist_sqr = len_sqr(to_light);
+        float dist = sqrtf(dist_sqr);
+        s.l = to_light / dist;
+        V3 dir_local = normalize(xf_vector(L.w2l, -s.l));
+        float ct = dir_local.z;
+        float falloff;
+        if (ct < L.cos_total_width)
+            falloff = 0.0f;
+        else if (ct > L.cos_falloff_start)
+            falloff = 1.0f;
+        else {
+            float delta = (ct - L.cos_total_width) / (L.cos_falloff_start - L.cos_total_width);
+            falloff = (delta * delta) * (delta * delta);
+        }
+        s.li = li * falloff / dist_sqr;
+        if (is_black(s.li)) s.has_vis = false;
+        s.p1 = lp;
+    } else if (L.kind == YK_LIGHT_DISTANT) {
+        s.li = li;
+        s.l = lp;  // w
+        s.p1 = sp + lp * 10000.0f;
+    } else {
+        V3 p = xf_point(L.s2w, V3{ux, 0.0f, uy});
+        V3 n = V3{L.n[0], L.n[1], L.n[2]};
+        V3 wi = normalize(p - sp);
+        float ndw = dot_nv(n, -wi);
+        s.li = ndw > 0.0f ? li : RGB{0.0f, 0.0f, 0.0f};
+        s.p1 = p;
+        s.area_light = index;
+        s.pdf = len_sqr(sp - p) / (fabsf(ndw) * L.area);
+        s.l = wi;
+    }
+    return s;
+}
+
+}  // namespace yk
