@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mray/s of the Path integrator at 1080p (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over the workload: every pixel x sample
+of the 1920x1080 film through raygen -> {trace, shade, shadow, accumulate} x 8 ->
+resolve, scene and camera already resident in HBM.  Workload (SURVEY.md §8(d),
+BASELINE.json configs[2], the configuration the >=1 Gray/s target is quoted on):
+~1 M-triangle synthetic scene, SAH BVH, Path 8 bounces, Stratified 8x8 = 64 spp.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the film's spiral
+tile list (film.rs:333-376) is dealt round-robin to the ranks, the scene is
+replicated, each rank renders its tiles into HBM and one RCCL gather moves the
+per-tile radiance to rank 0, which scatters it into the film (Film::update_tile).
+Total work is fixed -> "scaling": "strong".
+
+Metric = the reference's own: closest-hit rays / second (path.rs:87,
+app/window.rs:911-916); shadow rays are traced but not counted.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_COPY_CEILING_GBPS = 6290.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def workload(name):
+    from yuki_amd import core as yk
+    from yuki_amd import scenes
+
+    if name == "cfg3":
+        return dict(scene="cfg3", res=(1920, 1080), sampler=yk.SamplerType.Stratified((8, 8), True), depth=8,
+                    desc="cfg3: city 40x20 displaced icospheres, 1,024,012 triangles, SAH BVH (max_shapes_in_node 1), Path 8 bounces, Stratified 8x8, 1920x1080")
+    if name == "cfg2":
+        return dict(scene="cfg2", res=(1920, 1080), sampler=yk.SamplerType.Uniform(16), depth=8,
+                    desc="cfg2: bunny-class 69,312-triangle mesh, SAH BVH, Path 8 bounces, Uniform 16 spp, 1920x1080")
+    if name == "smoke":
+        return dict(scene="city-small", res=(320, 180), sampler=yk.SamplerType.Stratified((2, 2), True), depth=8,
+                    desc="smoke: city-small 7,692 triangles, Path 8, Stratified 2x2, 320x180")
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(sd, cam, sampler, integ, tiles, n_sample_tiles):
+    """The oracle (CPU restatement of the reference, kind 'port') timed on this
+    box's host cores on a bounded sample of the same workload."""
+    from oracle import binding as oracle
+
+    t0 = time.time()
+    osc = oracle.OracleScene(sd)
+    build_s = time.time() - t0
+    sample = tiles[:n_sample_tiles]
+    # render_manager.rs:78: num_cpus - 1 workers; a one-GPU box gives us a 16-core share
+    share = int(os.environ.get("YK_CPU_SHARE", min(16, os.cpu_count() or 2)))
+    cores = max(1, share - 1)
+    t0 = time.time()
+    _, rays, stats = osc.render_tiles(cam.matrices, sampler, integ, sample, n_threads=cores, want_stats=True)
+    dt = time.time() - t0
+    osc.close()
+    counters = dict(
+        node_tests_per_ray=stats.closest_node_tests / max(1, stats.closest_rays),
+        shape_tests_per_ray=stats.closest_shape_tests / max(1, stats.closest_rays),
+        shadow_rays_per_ray=stats.shadow_rays / max(1, stats.closest_rays),
+        shadow_node_tests_per_ray=stats.shadow_node_tests / max(1, stats.closest_rays),
+        shadow_shape_tests_per_ray=stats.shadow_shape_tests / max(1, stats.closest_rays),
+    )
+    return dict(value=rays / dt * 1e-6, unit="Mray/s", cores=cores, kind="port",
+                sample=f"first {len(sample)} spiral-order 16x16 tiles of the same frame at full spp ({rays} rays in {dt:.1f} s; oracle BVH build {build_s:.1f} s excluded)"), counters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--batch-paths", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-tiles", type=int, default=384)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from yuki_amd import scenes
+    from yuki_amd import core as yk
+    from yuki_amd import dist as ydist
+
+    wl = workload(args.workload)
+    t0 = time.time()
+    sd = scenes.by_name(wl["scene"])
+    gen_s = time.time() - t0
+    opts = {}
+    if args.batch_paths:
+        opts["batch_paths"] = args.batch_paths
+    ctx = yk.Context(local_rank, **opts)
+    scene = yk.Scene(ctx, sd)
+    info = scene.info()
+    fs = yk.FilmSettings(res=wl["res"], tile_dim=16)
+    cam = yk.Camera(sd.camera, fs)
+    sampler = wl["sampler"]
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=wl["depth"]))
+    it = yk.IntegratorType.instantiate(ctx, integ)
+    tiles = yk.film_tiles(fs)
+    spp = yk.samples_per_pixel(sampler)
+    if rank == 0:
+        log(f"[bench] scene {sd.name}: gen {gen_s:.2f}s, BVH build {info.build_seconds:.2f}s ({info.n_nodes} nodes, depth {info.tree_depth}), "
+            f"upload {info.upload_seconds:.2f}s, {info.device_bytes / 1e6:.0f} MB in HBM; {len(tiles)} tiles, {spp} spp")
+
+    # tile i -> rank i mod G (interleaved deal of the spiral order)
+    my_tiles = ydist.shard_tiles(tiles, rank, world)
+    slab_px = ydist.slab_pixels(tiles, world)
+    slab = torch.zeros(slab_px * 3, dtype=torch.float32, device=dev)
+    film = torch.zeros(wl["res"][1] * wl["res"][0] * 3, dtype=torch.float32, device=dev) if rank == 0 else None
+    gathered = [torch.zeros_like(slab) for _ in range(world)] if (rank == 0 and world > 1) else None
+
+    def step():
+        st = it.render_tiles_device(scene, cam, sampler, my_tiles, slab.data_ptr(), want_stats=True)  # syncs the render stream
+        if world > 1:
+            dist.gather(slab, gathered, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    tr = ydist.shard_tiles(tiles, r, world)
+                    yk.check(yk.lib().yk_film_update_tiles_device(ctx.h, tr.ctypes.data_as(ctypes.c_void_p), len(tr), ctypes.c_void_p(gathered[r].data_ptr()),
+                                                                   wl["res"][0], wl["res"][1], ctypes.c_void_p(film.data_ptr()), None), ctx.h)
+        else:
+            yk.check(yk.lib().yk_film_update_tiles_device(ctx.h, my_tiles.ctypes.data_as(ctypes.c_void_p), len(my_tiles), ctypes.c_void_p(slab.data_ptr()),
+                                                           wl["res"][0], wl["res"][1], ctypes.c_void_p(film.data_ptr()), None), ctx.h)
+        return st
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    rays = shadow = 0
+    t_trace = t_shadow = t_shade = t_dev = 0.0
+    launches = 0
+    for _ in range(args.steps):
+        st = step()
+        rays += st.rays
+        shadow += st.shadow_rays
+        t_trace += st.seconds_trace
+        t_shadow += st.seconds_shadow
+        t_shade += st.seconds_shade
+        t_dev += st.seconds_total
+        launches += st.trace_launches
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([rays, shadow], dtype=torch.int64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        rays_all, shadow_all = int(c[0].item()), int(c[1].item())
+    else:
+        rays_all, shadow_all = rays, shadow
+
+    if rank == 0:
+        film_mean = film.view(-1, 3).mean(dim=0).tolist()
+        value = rays_all / elapsed * 1e-6
+        cpu = None
+        counters = None
+        stored = os.path.join(ROOT, "profiles", f"oracle_counters_{args.workload}.json")
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, counters = cpu_baseline(sd, cam, sampler, integ, tiles, args.cpu_sample_tiles)
+            log(f"[bench] cpu_baseline {cpu['value']:.3f} Mray/s on {cpu['cores']} threads; oracle counters {counters}")
+        elif os.path.exists(stored):
+            counters = json.load(open(stored))["counters"]
+        roofline = None
+        if counters and t_trace > 0:
+            # dominant kernel = k_trace_closest.  Algorithmic bytes per ray it traces:
+            #   32 B per BVH node test + 36 B per leaf triangle test (the oracle's counters
+            #   on this scene/seed) + 32 B ray read + 16 B hit record   
+            b_closest = 32.0 * counters["node_tests_per_ray"] + 36.0 * counters["shape_tests_per_ray"] + 48.0
+            achieved = b_closest * rays / t_trace / 1e9
+            # whole-path figure of SURVEY §8(d): B_ray = 32*N_node + 36*N_tri + 304 with shadow tests attributed
+            b_ray = 32.0 * (counters["node_tests_per_ray"] + counters["shadow_node_tests_per_ray"]) + 36.0 * (counters["shape_tests_per_ray"] + counters["shadow_shape_tests_per_ray"]) + 304.0
+            pmc = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch") if os.path.exists(pmc) else None
+            roofline = dict(bound="hbm", kernel="k_trace_closest", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s", frac=achieved / HBM_PEAK_GBPS,
+                            traffic=traffic, bytes_per_ray=b_closest, avg_launch_ms=t_trace / max(1, launches) * 1e3, launches=launches,
+                            rays_per_launch=rays / max(1, launches), frac_of_copy_ceiling=achieved / HBM_COPY_CEILING_GBPS,
+                            path_bytes_per_ray=b_ray, path_achieved=b_ray * (rays / max(t_dev, 1e-9)) / 1e9,
+                            path_frac=b_ray * (rays / max(t_dev, 1e-9)) / 1e9 / HBM_PEAK_GBPS)
+        out = {
+            "metric": "Mray/s (primary+secondary), Path integrator @1080p",
+            "value": value,
+            "unit": "Mray/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl["desc"], "triangles": sd.n_triangles, "spp": spp, "max_depth": wl["depth"], "tiles": int(len(tiles)),
+                       "partition": f"spiral tiles dealt round-robin to {world} rank(s), RCCL gather to rank 0" if world > 1 else "single GPU"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "extra": {"rays_per_step": rays_all // args.steps, "shadow_rays_per_step": shadow_all // args.steps,
+                      "shadow_Mray_per_s": shadow_all / elapsed * 1e-6, "rank0_device_s_per_step": t_dev / args.steps,
+                      "rank0_trace_s": t_trace / args.steps, "rank0_shadow_s": t_shadow / args.steps, "rank0_shade_s": t_shade / args.steps,
+                      "film_mean_rgb": film_mean, "bvh_build_s": info.build_seconds, "scene_upload_s": info.upload_seconds},
+        }
+        print(json.dumps(out), flush=True)
+    scene.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,7 +96,7 @@ class SceneData:
     def light_descs(self, factory):
         """Build LightDesc structs through `factory` — an object exposing
         make_rect_light / make_spot_light / make_point_light (the HIP library's
-        host helpers, or the oracle's for the checker side)."""
+        host helpers; the tests pass the checker.s own)."""
         arr = (abi.LightDesc * max(1, len(self.lights)))()
         for k, l in enumerate(self.lights):
             if l["kind"] == "rect":
@@ -114,7 +114,7 @@ class SceneData:
         return arr
 
     def desc(self, factory):
-        """(SceneDesc, keepalive) for yk_scene_create / orc_scene_create."""
+        """(SceneDesc, keepalive) for yk_scene_create."""
         keep = {}
         d = abi.SceneDesc()
         keep["points"] = np.ascontiguousarray(self.points, dtype=F)
