@@ -124,6 +124,28 @@ def test_result_independent_of_batch_size(yk, oracle):
         assert np.array_equal(_bits(o), _bits(outs[0][0]))
 
 
+def test_many_tiles_per_block_is_deterministic(yk):
+    """8.3 M camera samples: every shade block runs many grid-stride iterations and
+    flushes its LDS staging buffers repeatedly; one batch vs eight batches must
+    agree bit for bit (guards the staging/flush synchronisation)."""
+    sd = scenes.by_name("city-small")
+    fs = yk.FilmSettings(res=(1920, 1080))
+    sampler = yk.SamplerType.Stratified((2, 2), True, SEED)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=8))
+    outs = []
+    for batch in (16 << 20, 1 << 20):
+        c = yk.Context(0, batch_paths=batch)
+        sc = yk.Scene(c, sd)
+        out, st = yk.IntegratorType.instantiate(c, integ).render_tiles(sc, yk.Camera(sd.camera, fs), sampler, yk.film_tiles(fs))
+        outs.append((out, st.rays, st.shadow_rays, st.batches))
+        sc.close()
+        c.close()
+    assert outs[0][3] == 1 and outs[1][3] == 8
+    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+    assert np.array_equal(_bits(outs[0][0]), _bits(outs[1][0]))
+    assert np.isfinite(outs[0][0]).all()
+
+
 def test_li_matches_render(ctx, yk, oracle):
     """Integrator::li on caller-supplied camera rays == what render computes for them."""
     sd = scenes.by_name("city-tiny")

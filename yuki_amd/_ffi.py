@@ -10,7 +10,7 @@ import subprocess
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyuki_hip.so")
+LIB_PATH = os.environ.get("YK_LIB_PATH") or os.path.join(_HERE, "libyuki_hip.so")  # override: kernel-variant experiments
 _LIB = None
 
 YK_OK = 0

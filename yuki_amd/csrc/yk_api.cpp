@@ -50,7 +50,7 @@ struct yk_context {
     std::string last_error;
     int n_cu = 256;
     // options
-    int64_t batch_paths = 4 << 20;
+    int64_t batch_paths = 128 << 20;
     int64_t sample_buf_cap = (int64_t)64 << 30;
     int64_t time_kernels = 1;
     // work buffers
@@ -529,7 +529,7 @@ static yk_status ensure_work_buffers(yk_context* ctx, size_t paths, unsigned n_l
     return YK_OK;
 }
 
-static unsigned trace_grid(const yk_context* ctx) { return (unsigned)ctx->n_cu * 5u; }
+static unsigned trace_grid(const yk_context* ctx) { return (unsigned)ctx->n_cu * trace_blocks_per_cu(); }
 
 static yk_status ensure_spill(yk_context* ctx) {
     size_t threads = (size_t)trace_grid(ctx) * trace_block_size();
@@ -664,6 +664,15 @@ yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const y
 
     const bool is_path = prm.integrator == YK_INTEGRATOR_PATH;
     size_t batch = (size_t)std::min<uint64_t>((uint64_t)ctx->batch_paths, total_px * spp);
+    {
+        // keep the per-batch work buffers (148 + 53*n_lights bytes per path) within half of the free HBM
+        size_t free_b = 0, total_b = 0;
+        if (batch > ctx->cap_paths && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t per_path = 148 + 53 * (size_t)std::max(1u, scene->n_lights);
+            const size_t fit = (free_b / 2) / per_path;
+            if (fit >= 65536 && batch > fit) batch = fit;
+        }
+    }
     yk_status wb = ensure_work_buffers(ctx, batch, scene->n_lights);
     if (wb != YK_OK) return wb;
     if ((wb = ensure_spill(ctx)) != YK_OK) return wb;

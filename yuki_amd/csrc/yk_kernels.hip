@@ -19,27 +19,9 @@
 #include "yk_geom.h"
 #include "yk_kernels.h"
 #include "yk_rng.h"
+#include "yk_wave.h"
 
 namespace yk {
-
-#define YK_WAVE 64
-
-__device__ __forceinline__ V3 f4_xyz(float4 v) { return V3{v.x, v.y, v.z}; }
-__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & (YK_WAVE - 1); }
-
-// wave-level append: every lane of the wave calls this in converged control flow;
-// lanes with `want` get consecutive slots from one atomic per wave.
-__device__ __forceinline__ unsigned wave_append(bool want, unsigned* counter) {
-    unsigned long long mask = __ballot(want);
-    unsigned total = (unsigned)__popcll(mask);
-    unsigned lane = lane_id();
-    unsigned prefix = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-    unsigned base = 0;
-    int leader = total ? (int)__ffsll((long long)mask) - 1 : 0;
-    if (total && (int)lane == leader) base = atomicAdd(counter, total);
-    base = __shfl(base, leader);
-    return base + prefix;
-}
 
 // ------------------------------------------------------------------ pixel table
 // chunk-local pixel index -> pixel coordinates, tile-major / row-major in tile
@@ -112,264 +94,77 @@ __global__ void k_raygen_user(RenderParams prm, const float* ray_o, const float*
     sample_buf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
-// ------------------------------------------------------------------ traversal
-// Traversal stack: entries [0, LDS_DEPTH) live in LDS laid out [depth][thread]
-// (conflict-free: the bank depends on the lane only), deeper entries overflow to
-// a per-thread slice of HBM scratch.  Capacity 64 like the reference (bvh.rs:172).
-#define YK_STACK_CAP 64
-
-template <int BLOCK, int LDS_DEPTH> struct TravStack {
-    uint2* lds;      // [LDS_DEPTH][BLOCK]
-    uint2* spill;    // [YK_STACK_CAP - LDS_DEPTH][spill_stride]
-    unsigned spill_stride, gtid;
-    __device__ __forceinline__ void push(int sp, unsigned ref, float tmin) {
-        uint2 e = make_uint2(ref, __float_as_uint(tmin));
-        if (sp < LDS_DEPTH)
-            lds[sp * BLOCK + threadIdx.x] = e;
-        else
-            spill[(size_t)(sp - LDS_DEPTH) * spill_stride + gtid] = e;
-    }
-    __device__ __forceinline__ uint2 at(int sp) const {
-        if (sp < LDS_DEPTH) return lds[sp * BLOCK + threadIdx.x];
-        return spill[(size_t)(sp - LDS_DEPTH) * spill_stride + gtid];
-    }
-};
-
-struct NodeBoxes {
-    V3 lo0, hi0, lo1, hi1;
-    unsigned ref0, ref1, axis;
-};
-__device__ __forceinline__ NodeBoxes load_node(const DevNode* nodes, unsigned idx) {
-    const float4* q = reinterpret_cast<const float4*>(nodes + idx);
-    float4 a = q[0], b = q[1], c = q[2];
-    uint4 d = reinterpret_cast<const uint4*>(q)[3];
-    NodeBoxes n;
-    n.lo0 = V3{a.x, a.y, a.z};
-    n.hi0 = V3{a.w, b.x, b.y};
-    n.lo1 = V3{b.z, b.w, c.x};
-    n.hi1 = V3{c.y, c.z, c.w};
-    n.ref0 = d.x;
-    n.ref1 = d.y;
-    n.axis = d.z;
-    return n;
-}
-
-// Closest hit with the reference's visiting order (near child first by the sign
-// of the direction along the split axis, far child deferred, leaves in shape
-// order, a later hit with t == t_max replaces the earlier one).  Box tests of a
-// deferred child are evaluated when its parent is visited and completed at pop
-// time by `tmin <= t_max`, which is exactly the reference's test at pop time
-// because t_max only shrinks (DESIGN.md §traversal equivalence).
-template <int BLOCK, int LDS_DEPTH, bool STATS>
-__device__ __forceinline__ void traverse_closest(const DevScene& sc, V3 o, V3 d, float t_max_in, TravStack<BLOCK, LDS_DEPTH>& stk, int& out_tri,
-                                                 TriHit& out_hit, unsigned& node_tests, unsigned& node_hits, unsigned& shape_tests,
-                                                 unsigned* err) {
-    V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-    bool neg[3] = {inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f};
-    RayTri rt = ray_tri_setup(d);
-    float t_max = t_max_in;
-    out_tri = -1;
-    int sp = 0;
-    float tmin;
-    if (STATS) node_tests += 1;
-    if (!slab(V3{sc.root_bmin[0], sc.root_bmin[1], sc.root_bmin[2]}, V3{sc.root_bmax[0], sc.root_bmax[1], sc.root_bmax[2]}, o, inv, t_max, tmin)) return;
-    if (STATS) node_hits += 1;
-    unsigned cur = sc.root_ref;
-    for (;;) {
-        if (!(cur & YK_LEAF_BIT)) {
-            NodeBoxes nb = load_node(sc.nodes, cur);
-            float t0, t1;
-            bool h0 = slab(nb.lo0, nb.hi0, o, inv, t_max, t0);
-            bool h1 = slab(nb.lo1, nb.hi1, o, inv, t_max, t1);
-            bool swap = neg[nb.axis];
-            unsigned near_ref = swap ? nb.ref1 : nb.ref0, far_ref = swap ? nb.ref0 : nb.ref1;
-            bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
-            float far_t = swap ? t0 : t1;
-            if (STATS) {
-                node_tests += 1;  // the near child is tested right away; the far one is counted when popped
-                if (near_hit) node_hits += 1;
-            }
-            if (STATS || far_hit) {
-                // with STATS the far child is pushed even when its box is missed so
-                // that the test is counted at pop time like the reference does
-                if (sp >= YK_STACK_CAP) {
-                    atomicOr(err, 1u);
-                    return;
-                }
-                stk.push(sp, far_ref, far_hit ? far_t : __builtin_nanf(""));
-                ++sp;
-            }
-            if (near_hit) {
-                cur = near_ref;
-                continue;
-            }
-        } else {
-            unsigned prim = cur & ~YK_LEAF_BIT;
-            for (;;) {
-                float4 v0 = sc.tris[3 * prim], v1 = sc.tris[3 * prim + 1], v2 = sc.tris[3 * prim + 2];
-                TriHit h;
-                if (STATS) shape_tests += 1;
-                if (tri_intersect(o, rt, t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h)) {
-                    out_hit = h;
-                    out_tri = (int)__float_as_uint(v1.w);
-                    t_max = h.t;
-                }
-                if (__float_as_uint(v2.w) & 1u) break;
-                ++prim;
-            }
-        }
-        // pop
-        bool found = false;
-        while (sp > 0) {
-            --sp;
-            uint2 e = stk.at(sp);
-            float et = __uint_as_float(e.y);
-            if (STATS) node_tests += 1;
-            if (et <= t_max) {
-                if (STATS) node_hits += 1;
-                cur = e.x;
-                found = true;
-                break;
-            }
-        }
-        if (!found) return;
-    }
-}
-
-// any_intersect: boolean, order independent; t_max is fixed so a deferred
-// child's box test is final.
-template <int BLOCK, int LDS_DEPTH>
-__device__ __forceinline__ bool traverse_any(const DevScene& sc, V3 o, V3 d, float t_max, int area_light, TravStack<BLOCK, LDS_DEPTH>& stk,
-                                             unsigned* err) {
-    V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-    bool neg[3] = {inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f};
-    RayTri rt = ray_tri_setup(d);
-    int sp = 0;
-    float tmin;
-    if (!slab(V3{sc.root_bmin[0], sc.root_bmin[1], sc.root_bmin[2]}, V3{sc.root_bmax[0], sc.root_bmax[1], sc.root_bmax[2]}, o, inv, t_max, tmin)) return false;
-    unsigned cur = sc.root_ref;
-    for (;;) {
-        if (!(cur & YK_LEAF_BIT)) {
-            NodeBoxes nb = load_node(sc.nodes, cur);
-            float t0, t1;
-            bool h0 = slab(nb.lo0, nb.hi0, o, inv, t_max, t0);
-            bool h1 = slab(nb.lo1, nb.hi1, o, inv, t_max, t1);
-            bool swap = neg[nb.axis];
-            unsigned near_ref = swap ? nb.ref1 : nb.ref0, far_ref = swap ? nb.ref0 : nb.ref1;
-            bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
-            if (near_hit) {
-                if (far_hit) {
-                    if (sp >= YK_STACK_CAP) {
-                        atomicOr(err, 1u);
-                        return true;
-                    }
-                    stk.push(sp, far_ref, 0.0f);
-                    ++sp;
-                }
-                cur = near_ref;
-                continue;
-            }
-            if (far_hit) {
-                cur = far_ref;
-                continue;
-            }
-        } else {
-            unsigned prim = cur & ~YK_LEAF_BIT;
-            for (;;) {
-                float4 v0 = sc.tris[3 * prim], v1 = sc.tris[3 * prim + 1], v2 = sc.tris[3 * prim + 2];
-                TriHit h;
-                if (tri_intersect(o, rt, t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h)) {
-                    // bvh.rs:269-280: a hit on the sampled area light's own surface does not occlude
-                    int prim_light = (int)__float_as_uint(v0.w);
-                    if (!(area_light >= 0 && prim_light >= 0 && prim_light == area_light)) return true;
-                }
-                if (__float_as_uint(v2.w) & 1u) break;
-                ++prim;
-            }
-        }
-        if (sp == 0) return false;
-        --sp;
-        cur = stk.at(sp).x;
-    }
-}
-
-// Persistent waves: each wave pulls 64 consecutive rays from a global head until
-// the queue (whose length only the device knows) is drained.
-template <int BLOCK, int LDS_DEPTH, bool STATS>
-__global__ __launch_bounds__(BLOCK) void k_trace_closest(DevScene sc, const float4* rayO, const float4* rayD, const float* t_max_opt,
-                                                         const unsigned* count_ptr, unsigned* head, int* hit_tri, float4* hit_out,
-                                                         uint4* stats_out, uint2* spill, unsigned spill_stride, unsigned* ctrl,
-                                                         unsigned long long* ray_counter) {
-    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
-    TravStack<BLOCK, LDS_DEPTH> stk;
-    stk.lds = lds_stack;
-    stk.spill = spill;
-    stk.spill_stride = spill_stride;
-    stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
-    const unsigned n = *count_ptr;
-    if (ray_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter, (unsigned long long)n);
-    for (;;) {
-        unsigned base = 0;
-        if (lane_id() == 0) base = atomicAdd(head, YK_WAVE);
-        base = __shfl(base, 0);
-        if (base >= n) break;
-        unsigned i = base + lane_id();
-        if (i < n) {
-            float4 ro = rayO[i], rd = rayD[i];
-            float tm = t_max_opt ? t_max_opt[i] : __builtin_inff();
-            int tri;
-            TriHit h = TriHit{0.0f, 0.0f, 0.0f, 0.0f};
-            unsigned nt = 0, nh = 0, st = 0;
-            traverse_closest<BLOCK, LDS_DEPTH, STATS>(sc, f4_xyz(ro), f4_xyz(rd), tm, stk, tri, h, nt, nh, st, ctrl + YK_CTRL_ERR);
-            hit_tri[i] = tri;
-            if (hit_out) hit_out[i] = make_float4(h.t, h.b0, h.b1, h.b2);
-            if (STATS) stats_out[i] = make_uint4(nt, nh, st, 0u);
-        }
-    }
-}
-
-template <int BLOCK, int LDS_DEPTH>
-__global__ __launch_bounds__(BLOCK) void k_trace_any(DevScene sc, const float4* shO, const float4* shD, const unsigned* queue,
-                                                     const unsigned* count_ptr, unsigned* head, unsigned char* vis, uint2* spill,
-                                                     unsigned spill_stride, unsigned* ctrl, unsigned long long* shadow_counter) {
-    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
-    TravStack<BLOCK, LDS_DEPTH> stk;
-    stk.lds = lds_stack;
-    stk.spill = spill;
-    stk.spill_stride = spill_stride;
-    stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
-    const unsigned n = *count_ptr;
-    if (shadow_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(shadow_counter, (unsigned long long)n);
-    for (;;) {
-        unsigned base = 0;
-        if (lane_id() == 0) base = atomicAdd(head, YK_WAVE);
-        base = __shfl(base, 0);
-        if (base >= n) break;
-        unsigned k = base + lane_id();
-        if (k < n) {
-            unsigned slot = queue ? queue[k] : k;
-            float4 so = shO[slot], sd = shD[slot];
-            bool occluded = traverse_any<BLOCK, LDS_DEPTH>(sc, f4_xyz(so), f4_xyz(sd), so.w, (int)__float_as_uint(sd.w), stk, ctrl + YK_CTRL_ERR);
-            if (queue) {
-                if (occluded) vis[slot] = 2;
-            } else {
-                vis[slot] = occluded ? 1 : 0;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------ shade
 // Path::li_internal for one vertex of every active path (path.rs:89-169).
-template <int BLOCK>
+//
+// Stream compaction: survivors and shadow rays are first appended to LDS staging
+// buffers (wave ballot + one LDS atomic per wave) and flushed to HBM in dense runs
+// of >= BLOCK entries with ONE global atomic per flush.  A global atomic per wave
+// per append saturated the counter word (~90 M atomics/s, MI355X_MICROARCH.md
+// "dequeue") and made this kernel atomic-bound (profiles/r01_a_*: 0.178 s/frame,
+// 79 % of wave cycles waiting).
+template <int CAP> struct ShadeStaging {
+    float4 pO[CAP], pD[CAP], pT[CAP];
+    uint4 pR[CAP];
+    float4 qO[CAP], qD[CAP];
+    unsigned qS[CAP];
+    unsigned fill_p, fill_q, gbase;
+};
+
+// every thread of the block calls this (converged); returns the staging position
+__device__ __forceinline__ unsigned block_append(bool want, unsigned* lds_fill) {
+    unsigned long long mask = __ballot(want);
+    unsigned total = (unsigned)__popcll(mask);
+    unsigned prefix = (unsigned)__popcll(mask & ((1ull << lane_id()) - 1ull));
+    unsigned base = 0;
+    if (total && lane_id() == 0) base = atomicAdd(lds_fill, total);
+    base = __shfl(base, 0);
+    return base + prefix;
+}
+
+template <int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                                                  PathBuffers cur, PathBuffers nxt,
                                                  const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis,
                                                  unsigned* shq, unsigned* ctrl, unsigned cur_slot) {
+    __shared__ ShadeStaging<CAP> stg;
     const unsigned n = ctrl[cur_slot];
     const unsigned nl = sc.n_lights;
     unsigned* next_count = ctrl + (cur_slot ^ 1u);
     unsigned* shq_count = ctrl + YK_CTRL_SHQ;
+    if (threadIdx.x == 0) {
+        stg.fill_p = 0;
+        stg.fill_q = 0;
+    }
+    __syncthreads();
+    // flush helpers (block-uniform control flow)
+    auto flush_q = [&](unsigned fill) {
+        if (threadIdx.x == 0) stg.gbase = atomicAdd(shq_count, fill);
+        __syncthreads();
+        const unsigned gb = stg.gbase;
+        for (unsigned k = threadIdx.x; k < fill; k += BLOCK) {
+            shO[gb + k] = stg.qO[k];
+            shD[gb + k] = stg.qD[k];
+            shq[gb + k] = stg.qS[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) stg.fill_q = 0;
+        __syncthreads();
+    };
+    auto flush_p = [&](unsigned fill) {
+        if (threadIdx.x == 0) stg.gbase = atomicAdd(next_count, fill);
+        __syncthreads();
+        const unsigned gb = stg.gbase;
+        for (unsigned k = threadIdx.x; k < fill; k += BLOCK) {
+            nxt.rayO[gb + k] = stg.pO[k];
+            nxt.rayD[gb + k] = stg.pD[k];
+            nxt.thru[gb + k] = stg.pT[k];
+            nxt.rngs[gb + k] = stg.pR[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) stg.fill_p = 0;
+        __syncthreads();
+    };
     // all lanes stay in the loop together so the ballots below see whole waves
     const unsigned n_round = (n + BLOCK - 1) / BLOCK * BLOCK;
     for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += gridDim.x * BLOCK) {
@@ -454,12 +249,20 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderParams prm, 
                 }
             }
             if (valid) vis[slot] = want ? 1 : 0;
-            unsigned q = wave_append(want, shq_count);
+            // shadow rays are appended densely (coalesced for the any-hit kernel); the
+            // contribution stays at its (path, light) slot for `accumulate`
+            __syncthreads();
+            {
+                const unsigned f = stg.fill_q;
+                __syncthreads();  // every wave has read the same fill before any wave appends again
+                if (f + BLOCK > CAP) flush_q(f);
+            }
+            unsigned q = block_append(want, &stg.fill_q);
             if (want) {
-                shO[slot] = make_float4(so.x, so.y, so.z, 0.9999f);
-                shD[slot] = make_float4(sd.x, sd.y, sd.z, __uint_as_float((unsigned)al));
+                stg.qO[q] = make_float4(so.x, so.y, so.z, 0.9999f);
+                stg.qD[q] = make_float4(sd.x, sd.y, sd.z, __uint_as_float((unsigned)al));
+                stg.qS[q] = slot;
                 shC[slot] = make_float4(contrib.r, contrib.g, contrib.b, 0.0f);
-                shq[q] = slot;
             }
         }
         if (valid) {
@@ -509,13 +312,25 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderParams prm, 
             pend[i] = make_float4(term.r, term.g, term.b, __uint_as_float(kind));
         }
         // ---- stream compaction of the survivors into the other buffer
-        unsigned j = wave_append(alive, next_count);
-        if (alive) {
-            nxt.rayO[j] = nO;
-            nxt.rayD[j] = nD;
-            nxt.thru[j] = nT;
-            nxt.rngs[j] = nR;
+        __syncthreads();
+        {
+            const unsigned f = stg.fill_p;
+            __syncthreads();
+            if (f + BLOCK > CAP) flush_p(f);
         }
+        unsigned j = block_append(alive, &stg.fill_p);
+        if (alive) {
+            stg.pO[j] = nO;
+            stg.pD[j] = nD;
+            stg.pT[j] = nT;
+            stg.pR[j] = nR;
+        }
+    }
+    __syncthreads();
+    {
+        const unsigned fq = stg.fill_q, fp = stg.fill_p;
+        if (fq) flush_q(fq);
+        if (fp) flush_p(fp);
     }
 }
 
@@ -692,12 +507,6 @@ __global__ void k_unpack_rays(size_t n, const float4* rayO, const float4* rayD, 
 // ------------------------------------------------------------------ launchers
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
-#define TRACE_BLOCK 256
-#define TRACE_LDS 16
-
-unsigned trace_block_size() { return TRACE_BLOCK; }
-unsigned trace_spill_depth() { return YK_STACK_CAP - TRACE_LDS; }
-
 void launch_pixel_table(hipStream_t s, const yk_tile* tiles, const uint32_t* tile_offset, uint32_t n_tiles, uint32_t n_pixels, uint32_t* pixel_xy) {
     if (!n_pixels) return;
     hipLaunchKernelGGL(k_pixel_table, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, tiles, tile_offset, n_tiles, n_pixels, pixel_xy);
@@ -711,27 +520,11 @@ void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, 
     hipLaunchKernelGGL(k_raygen_user, dim3(blocks_for(n, 256)), dim3(256), 0, s, prm, o, d, pixel, sample_index, dimension, n, out, sample_buf,
                        pixel_xy, ctrl);
 }
-void launch_trace_closest(hipStream_t s, unsigned grid, const DevScene& sc, const float4* rayO, const float4* rayD, const float* t_max_opt,
-                          const unsigned* count_ptr, unsigned* head, int* hit_tri, float4* hit_out, uint4* stats_out, uint2* spill,
-                          unsigned spill_stride, unsigned* ctrl, unsigned long long* ray_counter) {
-    if (stats_out)
-        hipLaunchKernelGGL((k_trace_closest<TRACE_BLOCK, TRACE_LDS, true>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, rayO, rayD, t_max_opt, count_ptr,
-                           head, hit_tri, hit_out, stats_out, spill, spill_stride, ctrl, ray_counter);
-    else
-        hipLaunchKernelGGL((k_trace_closest<TRACE_BLOCK, TRACE_LDS, false>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, rayO, rayD, t_max_opt, count_ptr,
-                           head, hit_tri, hit_out, stats_out, spill, spill_stride, ctrl, ray_counter);
-}
-void launch_trace_any(hipStream_t s, unsigned grid, const DevScene& sc, const float4* shO, const float4* shD, const unsigned* queue,
-                      const unsigned* count_ptr, unsigned* head, unsigned char* vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
-                      unsigned long long* shadow_counter) {
-    hipLaunchKernelGGL((k_trace_any<TRACE_BLOCK, TRACE_LDS>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, shO, shD, queue, count_ptr, head, vis, spill,
-                       spill_stride, ctrl, shadow_counter);
-}
 void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                   PathBuffers cur, PathBuffers nxt,
                   const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis, unsigned* shq, unsigned* ctrl,
                   unsigned cur_slot) {
-    hipLaunchKernelGGL((k_shade<256>), dim3(grid), dim3(256), 0, s, sc, prm, pixel_xy, sample_index_tab, cur, nxt, hit_tri, pend, shO, shD, shC, vis, shq, ctrl, cur_slot);
+    hipLaunchKernelGGL((k_shade<256, 512>), dim3(grid), dim3(256), 0, s, sc, prm, pixel_xy, sample_index_tab, cur, nxt, hit_tri, pend, shO, shD, shC, vis, shq, ctrl, cur_slot);
 }
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
                        const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* ctrl, unsigned cur_slot) {

@@ -50,9 +50,12 @@ YK_HD float dot(V3 a, V3 b) { return ((0.0f + a.x * b.x) + a.y * b.y) + a.z * b.
 // math/vector.rs:228-230 and math/normal.rs:57-59: no leading zero
 YK_HD float dot_nv(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 YK_HD float len_sqr(V3 a) { return dot(a, a); }
-// impl_vec_like.rs:223-228: sqrt in f64 then narrowed == correctly rounded sqrtf
-// (double rounding is innocuous for sqrt: 53 >= 2*24+2)
-YK_HD float length(V3 a) { return (float)sqrt((double)len_sqr(a)); }
+// impl_vec_like.rs:223-228: sqrt taken in f64 then narrowed.  That equals the
+// correctly rounded f32 sqrt (double rounding is innocuous for sqrt: 53 >= 2*24+2),
+// which is what sqrtf is on the host and — under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt — on gfx950 (tests/test_gpu_stages.py
+// checks both forms bit for bit), at a fraction of the f64 cost.
+YK_HD float length(V3 a) { return sqrtf(len_sqr(a)); }
 // impl_vec_like.rs:231-235: component-wise DIVISION
 YK_HD V3 normalize(V3 a) { return a / length(a); }
 // math/vector.rs:236-255: cross product evaluated in f64

@@ -129,7 +129,8 @@ YK_HD unsigned permutation_element(unsigned i, unsigned l, unsigned p) {
         i &= w;
         i ^= i >> 5;
     } while (i >= l);
-    return (i + p) % l;
+    unsigned s = i + p;
+    return (l & w) == 0u ? (s & w) : s % l;  // l power of two <=> (l & (l-1)) == 0 ; w = l-1 then
 }
 
 // Sampler parameters, constant over a render
@@ -183,8 +184,16 @@ YK_HD void sampler_get_2d(const SamplerCfg& c, SamplerState& s, float& ux, float
     u64 hashed = hash_pixel_dim_seed(s.px, s.py, s.dimension, c.seed);
     unsigned stratum = permutation_element(s.sample_index, c.spp, (unsigned)hashed);
     s.dimension += 2;
-    unsigned x = stratum % c.nx;
-    unsigned y = stratum / c.ny;  // sic, stratified.rs:128
+    // x = stratum % nx ; y = stratum / ny (sic, stratified.rs:128); shifts when both
+    // are powers of two (the usual 8x8 / 16x16), same values
+    unsigned x, y;
+    if (((c.nx & (c.nx - 1u)) | (c.ny & (c.ny - 1u))) == 0u) {
+        x = stratum & (c.nx - 1u);
+        y = stratum >> (31 - __builtin_clz(c.ny));
+    } else {
+        x = stratum % c.nx;
+        y = stratum / c.ny;
+    }
     float dx = c.jitter ? pcg_f32(s.rng) : 0.5f;
     float dy = c.jitter ? pcg_f32(s.rng) : 0.5f;
     ux = ((float)x + dx) / (float)c.nx;

@@ -1,0 +1,550 @@
+// yk_trace.hip — BVH traversal kernels for gfx950.
+//
+//   k_trace_closest_pt / k_trace_any_pt   production kernels: persistent waves,
+//       per-lane ray replacement with software prefetch, wave-uniform choice
+//       between an interior-node step and a leaf step (LDS-staged stacks)
+//   k_trace_closest<STATS> / k_trace_any  plain one-ray-per-lane loops; the STATS
+//       flavour reproduces IntersectionResult's counters (bvh.rs:167-179) for the
+//       BVHIntersections integrator and the parity tests
+//
+// Both families implement BoundingVolumeHierarchy::intersect (bvh.rs:160-232) and
+// ::any_intersect (bvh.rs:235-302) with the reference's visiting order.
+#include <hip/hip_runtime.h>
+
+#include "yk_device.h"
+#include "yk_geom.h"
+#include "yk_kernels.h"
+#include "yk_wave.h"
+
+namespace yk {
+
+// ------------------------------------------------------------------ traversal
+// Traversal stack: entries [0, LDS_DEPTH) live in LDS laid out [depth][thread]
+// (conflict-free: the bank depends on the lane only), deeper entries overflow to
+// a per-thread slice of HBM scratch.  Capacity 64 like the reference (bvh.rs:172).
+#define YK_STACK_CAP 64
+
+template <int BLOCK, int LDS_DEPTH> struct TravStack {
+    uint2* lds;      // [LDS_DEPTH][BLOCK]
+    uint2* spill;    // [YK_STACK_CAP - LDS_DEPTH][spill_stride]
+    unsigned spill_stride, gtid;
+    __device__ __forceinline__ void push(int sp, unsigned ref, float tmin) {
+        uint2 e = make_uint2(ref, __float_as_uint(tmin));
+        if (sp < LDS_DEPTH)
+            lds[sp * BLOCK + threadIdx.x] = e;
+        else
+            spill[(size_t)(sp - LDS_DEPTH) * spill_stride + gtid] = e;
+    }
+    __device__ __forceinline__ uint2 at(int sp) const {
+        if (sp < LDS_DEPTH) return lds[sp * BLOCK + threadIdx.x];
+        return spill[(size_t)(sp - LDS_DEPTH) * spill_stride + gtid];
+    }
+};
+
+struct NodeBoxes {
+    V3 lo0, hi0, lo1, hi1;
+    unsigned ref0, ref1, axis;
+};
+__device__ __forceinline__ NodeBoxes load_node(const DevNode* nodes, unsigned idx) {
+    const float4* q = reinterpret_cast<const float4*>(nodes + idx);
+    float4 a = q[0], b = q[1], c = q[2];
+    uint4 d = reinterpret_cast<const uint4*>(q)[3];
+    NodeBoxes n;
+    n.lo0 = V3{a.x, a.y, a.z};
+    n.hi0 = V3{a.w, b.x, b.y};
+    n.lo1 = V3{b.z, b.w, c.x};
+    n.hi1 = V3{c.y, c.z, c.w};
+    n.ref0 = d.x;
+    n.ref1 = d.y;
+    n.axis = d.z;
+    return n;
+}
+
+// Closest hit with the reference's visiting order (near child first by the sign
+// of the direction along the split axis, far child deferred, leaves in shape
+// order, a later hit with t == t_max replaces the earlier one).  Box tests of a
+// deferred child are evaluated when its parent is visited and completed at pop
+// time by `tmin <= t_max`, which is exactly the reference's test at pop time
+// because t_max only shrinks (DESIGN.md §traversal equivalence).
+template <int BLOCK, int LDS_DEPTH, bool STATS>
+__device__ __forceinline__ void traverse_closest(const DevScene& sc, V3 o, V3 d, float t_max_in, TravStack<BLOCK, LDS_DEPTH>& stk, int& out_tri,
+                                                 TriHit& out_hit, unsigned& node_tests, unsigned& node_hits, unsigned& shape_tests,
+                                                 unsigned* err) {
+    V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    bool neg[3] = {inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f};
+    RayTri rt = ray_tri_setup(d);
+    float t_max = t_max_in;
+    out_tri = -1;
+    int sp = 0;
+    float tmin;
+    if (STATS) node_tests += 1;
+    if (!slab(V3{sc.root_bmin[0], sc.root_bmin[1], sc.root_bmin[2]}, V3{sc.root_bmax[0], sc.root_bmax[1], sc.root_bmax[2]}, o, inv, t_max, tmin)) return;
+    if (STATS) node_hits += 1;
+    unsigned cur = sc.root_ref;
+    for (;;) {
+        if (!(cur & YK_LEAF_BIT)) {
+            NodeBoxes nb = load_node(sc.nodes, cur);
+            float t0, t1;
+            bool h0 = slab(nb.lo0, nb.hi0, o, inv, t_max, t0);
+            bool h1 = slab(nb.lo1, nb.hi1, o, inv, t_max, t1);
+            bool swap = neg[nb.axis];
+            unsigned near_ref = swap ? nb.ref1 : nb.ref0, far_ref = swap ? nb.ref0 : nb.ref1;
+            bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
+            float far_t = swap ? t0 : t1;
+            if (STATS) {
+                node_tests += 1;  // the near child is tested right away; the far one is counted when popped
+                if (near_hit) node_hits += 1;
+            }
+            if (STATS || far_hit) {
+                // with STATS the far child is pushed even when its box is missed so
+                // that the test is counted at pop time like the reference does
+                if (sp >= YK_STACK_CAP) {
+                    atomicOr(err, 1u);
+                    return;
+                }
+                stk.push(sp, far_ref, far_hit ? far_t : __builtin_nanf(""));
+                ++sp;
+            }
+            if (near_hit) {
+                cur = near_ref;
+                continue;
+            }
+        } else {
+            unsigned prim = cur & ~YK_LEAF_BIT;
+            for (;;) {
+                float4 v0 = sc.tris[3 * prim], v1 = sc.tris[3 * prim + 1], v2 = sc.tris[3 * prim + 2];
+                TriHit h;
+                if (STATS) shape_tests += 1;
+                if (tri_intersect(o, rt, t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h)) {
+                    out_hit = h;
+                    out_tri = (int)__float_as_uint(v1.w);
+                    t_max = h.t;
+                }
+                if (__float_as_uint(v2.w) & 1u) break;
+                ++prim;
+            }
+        }
+        // pop
+        bool found = false;
+        while (sp > 0) {
+            --sp;
+            uint2 e = stk.at(sp);
+            float et = __uint_as_float(e.y);
+            if (STATS) node_tests += 1;
+            if (et <= t_max) {
+                if (STATS) node_hits += 1;
+                cur = e.x;
+                found = true;
+                break;
+            }
+        }
+        if (!found) return;
+    }
+}
+
+
+// ------------------------------------------------------------------ persistent-thread traversal
+// A wave owns 64 ray slots.  Work arrives in CHUNK-sized index ranges claimed with
+// one atomic on the queue head; inside a chunk indices are handed to lanes by a
+// wave-local cursor.  Every lane keeps the NEXT ray it will trace already loaded
+// in registers (issued as soon as PF_MIN lanes lack one, consumed iterations
+// later), so replacing a finished ray costs no memory round trip: with plain
+// "fetch when idle" the wave stalled 2-4 us per refill and lost more than the
+// idle lanes had cost (profiles/r01_b_sweep.txt).  Each iteration the wave then
+// runs ONE of two bodies — an interior-node step for all lanes on interior nodes,
+// or, once LEAF_MIN lanes are parked on leaves (or none is on a node), the leaf
+// intersection for the parked lanes — so neither body executes at a handful of
+// lanes (lane utilisation of the plain loop: 26 %, profiles/r01_a_pmc_summary.json).
+// Per-ray arithmetic and visiting order are exactly those of traverse_closest /
+// traverse_any above.
+struct LaneRay {
+    V3 o, inv;
+    RayTri rt;
+    float t_max;
+    unsigned negmask;
+};
+
+__device__ __forceinline__ void lane_ray_setup(LaneRay& r, V3 o, V3 d, float t_max) {
+    r.o = o;
+    r.inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    r.negmask = (r.inv.x < 0.0f ? 1u : 0u) | (r.inv.y < 0.0f ? 2u : 0u) | (r.inv.z < 0.0f ? 4u : 0u);
+    r.rt = ray_tri_setup(d);
+    r.t_max = t_max;
+}
+
+// pops until an entry whose stored entry distance still satisfies tmin <= t_max
+template <int BLOCK, int LDS_DEPTH> __device__ __forceinline__ bool pop_closest(TravStack<BLOCK, LDS_DEPTH>& stk, int& sp, float t_max, unsigned& cur) {
+    while (sp > 0) {
+        --sp;
+        uint2 e = stk.at(sp);
+        if (__uint_as_float(e.y) <= t_max) {
+            cur = e.x;
+            return true;
+        }
+    }
+    return false;
+}
+
+// Wave-local work distribution: claims CHUNK indices at a time from *head.
+struct ChunkCursor {
+    unsigned cur, end;  // wave-uniform
+    bool exhausted;
+    __device__ __forceinline__ void init() {
+        cur = end = 0;
+        exhausted = false;
+    }
+    // hands `want` lanes consecutive indices; returns the index of this lane or
+    // 0xffffffff.  All lanes of the wave call it (converged).
+    template <int CHUNK> __device__ __forceinline__ unsigned take(bool want, unsigned n, unsigned* head) {
+        unsigned long long mask = __ballot(want);
+        if (mask == 0ull || exhausted) return 0xffffffffu;
+        if (cur >= end) {
+            unsigned base = 0;
+            if (lane_id() == 0) base = atomicAdd(head, (unsigned)CHUNK);
+            base = __shfl(base, 0);
+            if (base >= n) {
+                exhausted = true;
+                return 0xffffffffu;
+            }
+            cur = base;
+            end = base + (unsigned)CHUNK < n ? base + (unsigned)CHUNK : n;
+        }
+        unsigned rank = (unsigned)__popcll(mask & ((1ull << lane_id()) - 1ull));
+        unsigned idx = cur + rank;
+        unsigned total = (unsigned)__popcll(mask);
+        cur = cur + total < end ? cur + total : end;
+        return (want && idx < end) ? idx : 0xffffffffu;
+    }
+};
+
+template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int CHUNK>
+__global__ __launch_bounds__(BLOCK) void k_trace_closest_pt(DevScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
+                                                            const float* __restrict__ t_max_opt, const unsigned* count_ptr, unsigned* head,
+                                                            int* __restrict__ hit_tri, float4* __restrict__ hit_out, uint2* spill,
+                                                            unsigned spill_stride, unsigned* ctrl, unsigned long long* ray_counter) {
+    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    TravStack<BLOCK, LDS_DEPTH> stk;
+    stk.lds = lds_stack;
+    stk.spill = spill;
+    stk.spill_stride = spill_stride;
+    stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
+    const unsigned n = *count_ptr;
+    if (ray_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter, (unsigned long long)n);
+    const V3 root_lo = V3{sc.root_bmin[0], sc.root_bmin[1], sc.root_bmin[2]}, root_hi = V3{sc.root_bmax[0], sc.root_bmax[1], sc.root_bmax[2]};
+
+    ChunkCursor work;
+    work.init();
+    bool active = false, pf_valid = false;
+    float4 pf_o = make_float4(0, 0, 0, 0), pf_d = make_float4(0, 0, 1, 0);
+    float pf_t = 0.0f;
+    unsigned pf_idx = 0;
+    LaneRay r;
+    r.o = r.inv = V3{0, 0, 0};
+    r.rt = RayTri{0, 1, 2, 0, 0, 0};
+    r.t_max = 0.0f;
+    r.negmask = 0;
+    unsigned ray_i = 0, cur = 0;
+    int sp = 0, best = -1;
+    TriHit best_hit = TriHit{0, 0, 0, 0};
+
+    for (;;) {
+        // ---- start prefetched rays once START_MIN lanes are idle (the setup code —
+        // six IEEE divisions and the root test — runs divergently, so it is batched)
+        const bool startable = !active && pf_valid;
+        const bool go = (unsigned)__popcll(__ballot(startable)) >= (unsigned)START_MIN || !__any(active);
+        if (go && startable) {
+            pf_valid = false;
+            lane_ray_setup(r, f4_xyz(pf_o), f4_xyz(pf_d), pf_t);
+            ray_i = pf_idx;
+            float tmin;
+            if (slab(root_lo, root_hi, r.o, r.inv, r.t_max, tmin)) {
+                active = true;
+                cur = sc.root_ref;
+                sp = 0;
+                best = -1;
+            } else {
+                hit_tri[ray_i] = -1;
+            }
+        }
+        // ---- top up the prefetch registers (loads are consumed in a later iteration)
+        {
+            unsigned n_need = (unsigned)__popcll(__ballot(!pf_valid));
+            if (!work.exhausted && (n_need >= (unsigned)PF_MIN || !__any(active))) {
+                unsigned idx = work.take<CHUNK>(!pf_valid, n, head);
+                if (idx != 0xffffffffu) {
+                    pf_o = rayO[idx];
+                    pf_d = rayD[idx];
+                    pf_t = t_max_opt ? t_max_opt[idx] : __builtin_inff();
+                    pf_idx = idx;
+                    pf_valid = true;
+                }
+            }
+        }
+        if (!__any(active)) {
+            if (work.exhausted && !__any(pf_valid)) break;
+            continue;
+        }
+        // ---- one step, chosen for the whole wave
+        const bool on_leaf = active && (cur & YK_LEAF_BIT);
+        const bool on_node = active && !(cur & YK_LEAF_BIT);
+        const unsigned n_leaf = (unsigned)__popcll(__ballot(on_leaf));
+        if (__any(on_node) && n_leaf < (unsigned)LEAF_MIN) {
+            if (on_node) {
+                NodeBoxes nb = load_node(sc.nodes, cur);
+                float t0, t1;
+                bool h0 = slab(nb.lo0, nb.hi0, r.o, r.inv, r.t_max, t0);
+                bool h1 = slab(nb.lo1, nb.hi1, r.o, r.inv, r.t_max, t1);
+                bool swap = (r.negmask >> nb.axis) & 1u;
+                unsigned near_ref = swap ? nb.ref1 : nb.ref0, far_ref = swap ? nb.ref0 : nb.ref1;
+                bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
+                float far_t = swap ? t0 : t1;
+                if (near_hit) {
+                    if (far_hit) {
+                        if (sp >= YK_STACK_CAP) {
+                            atomicOr(ctrl + YK_CTRL_ERR, 1u);
+                            sp = 0;  // abandon this ray; the host reports YK_ERR_STACK_OVERFLOW
+                        } else {
+                            stk.push(sp, far_ref, far_t);
+                            ++sp;
+                        }
+                    }
+                    cur = near_ref;
+                } else if (far_hit) {
+                    cur = far_ref;  // no intervening leaf can shrink t_max: the test result is final
+                } else if (!pop_closest(stk, sp, r.t_max, cur)) {
+                    hit_tri[ray_i] = best;
+                    if (hit_out) hit_out[ray_i] = make_float4(best_hit.t, best_hit.b0, best_hit.b1, best_hit.b2);
+                    active = false;
+                }
+            }
+        } else if (on_leaf) {
+            unsigned prim = cur & ~YK_LEAF_BIT;
+            for (;;) {
+                float4 v0 = sc.tris[3 * prim], v1 = sc.tris[3 * prim + 1], v2 = sc.tris[3 * prim + 2];
+                TriHit h;
+                if (tri_intersect(r.o, r.rt, r.t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h)) {
+                    best_hit = h;
+                    best = (int)__float_as_uint(v1.w);
+                    r.t_max = h.t;
+                }
+                if (__float_as_uint(v2.w) & 1u) break;
+                ++prim;
+            }
+            if (!pop_closest(stk, sp, r.t_max, cur)) {
+                hit_tri[ray_i] = best;
+                if (hit_out) hit_out[ray_i] = make_float4(best_hit.t, best_hit.b0, best_hit.b1, best_hit.b2);
+                active = false;
+            }
+        }
+    }
+}
+
+// Shadow rays: shO/shD are dense (compacted by `shade`); slot_of[k] is where the
+// verdict goes (vis[slot] = 2 when occluded); slot_of == NULL (API mode): vis[k] = 0/1.
+template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int CHUNK>
+__global__ __launch_bounds__(BLOCK) void k_trace_any_pt(DevScene sc, const float4* __restrict__ shO, const float4* __restrict__ shD,
+                                                        const unsigned* __restrict__ slot_of, const unsigned* count_ptr, unsigned* head,
+                                                        unsigned char* __restrict__ vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
+                                                        unsigned long long* shadow_counter) {
+    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    TravStack<BLOCK, LDS_DEPTH> stk;
+    stk.lds = lds_stack;
+    stk.spill = spill;
+    stk.spill_stride = spill_stride;
+    stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
+    const unsigned n = *count_ptr;
+    if (shadow_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(shadow_counter, (unsigned long long)n);
+    const V3 root_lo = V3{sc.root_bmin[0], sc.root_bmin[1], sc.root_bmin[2]}, root_hi = V3{sc.root_bmax[0], sc.root_bmax[1], sc.root_bmax[2]};
+
+    ChunkCursor work;
+    work.init();
+    bool active = false, pf_valid = false;
+    float4 pf_o = make_float4(0, 0, 0, 0), pf_d = make_float4(0, 0, 1, 0);
+    unsigned pf_slot = 0;
+    LaneRay r;
+    r.o = r.inv = V3{0, 0, 0};
+    r.rt = RayTri{0, 1, 2, 0, 0, 0};
+    r.t_max = 0.0f;
+    r.negmask = 0;
+    unsigned slot = 0, cur = 0;
+    int sp = 0, area_light = -1;
+
+    for (;;) {
+        const bool startable = !active && pf_valid;
+        const bool go = (unsigned)__popcll(__ballot(startable)) >= (unsigned)START_MIN || !__any(active);
+        if (go && startable) {
+            pf_valid = false;
+            lane_ray_setup(r, f4_xyz(pf_o), f4_xyz(pf_d), pf_o.w);
+            area_light = (int)__float_as_uint(pf_d.w);
+            slot = pf_slot;
+            float tmin;
+            if (slab(root_lo, root_hi, r.o, r.inv, r.t_max, tmin)) {
+                active = true;
+                cur = sc.root_ref;
+                sp = 0;
+            } else if (!slot_of) {
+                vis[slot] = 0;
+            }
+        }
+        {
+            unsigned n_need = (unsigned)__popcll(__ballot(!pf_valid));
+            if (!work.exhausted && (n_need >= (unsigned)PF_MIN || !__any(active))) {
+                unsigned k = work.take<CHUNK>(!pf_valid, n, head);
+                if (k != 0xffffffffu) {
+                    pf_o = shO[k];
+                    pf_d = shD[k];
+                    pf_slot = slot_of ? slot_of[k] : k;
+                    pf_valid = true;
+                }
+            }
+        }
+        if (!__any(active)) {
+            if (work.exhausted && !__any(pf_valid)) break;
+            continue;
+        }
+        const bool on_leaf = active && (cur & YK_LEAF_BIT);
+        const bool on_node = active && !(cur & YK_LEAF_BIT);
+        const unsigned n_leaf = (unsigned)__popcll(__ballot(on_leaf));
+        if (__any(on_node) && n_leaf < (unsigned)LEAF_MIN) {
+            if (on_node) {
+                NodeBoxes nb = load_node(sc.nodes, cur);
+                float t0, t1;
+                bool h0 = slab(nb.lo0, nb.hi0, r.o, r.inv, r.t_max, t0);
+                bool h1 = slab(nb.lo1, nb.hi1, r.o, r.inv, r.t_max, t1);
+                bool swap = (r.negmask >> nb.axis) & 1u;
+                unsigned near_ref = swap ? nb.ref1 : nb.ref0, far_ref = swap ? nb.ref0 : nb.ref1;
+                bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
+                if (near_hit) {
+                    if (far_hit) {
+                        if (sp >= YK_STACK_CAP) {
+                            atomicOr(ctrl + YK_CTRL_ERR, 1u);
+                            sp = 0;
+                        } else {
+                            stk.push(sp, far_ref, 0.0f);
+                            ++sp;
+                        }
+                    }
+                    cur = near_ref;
+                } else if (far_hit) {
+                    cur = far_ref;
+                } else if (sp > 0) {
+                    --sp;
+                    cur = stk.at(sp).x;
+                } else {
+                    if (!slot_of) vis[slot] = 0;
+                    active = false;  // unoccluded
+                }
+            }
+        } else if (on_leaf) {
+            unsigned prim = cur & ~YK_LEAF_BIT;
+            bool occluded = false;
+            for (;;) {
+                float4 v0 = sc.tris[3 * prim], v1 = sc.tris[3 * prim + 1], v2 = sc.tris[3 * prim + 2];
+                TriHit h;
+                if (tri_intersect(r.o, r.rt, r.t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h)) {
+                    // bvh.rs:269-280: a hit on the sampled area light's own surface does not occlude
+                    int prim_light = (int)__float_as_uint(v0.w);
+                    if (!(area_light >= 0 && prim_light >= 0 && prim_light == area_light)) {
+                        occluded = true;
+                        break;
+                    }
+                }
+                if (__float_as_uint(v2.w) & 1u) break;
+                ++prim;
+            }
+            if (occluded) {
+                vis[slot] = slot_of ? 2 : 1;
+                active = false;
+            } else if (sp > 0) {
+                --sp;
+                cur = stk.at(sp).x;
+            } else {
+                if (!slot_of) vis[slot] = 0;
+                active = false;
+            }
+        }
+    }
+}
+
+// Persistent waves: each wave pulls 64 consecutive rays from a global head until
+// the queue (whose length only the device knows) is drained.
+template <int BLOCK, int LDS_DEPTH, bool STATS>
+__global__ __launch_bounds__(BLOCK) void k_trace_closest(DevScene sc, const float4* rayO, const float4* rayD, const float* t_max_opt,
+                                                         const unsigned* count_ptr, unsigned* head, int* hit_tri, float4* hit_out,
+                                                         uint4* stats_out, uint2* spill, unsigned spill_stride, unsigned* ctrl,
+                                                         unsigned long long* ray_counter) {
+    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    TravStack<BLOCK, LDS_DEPTH> stk;
+    stk.lds = lds_stack;
+    stk.spill = spill;
+    stk.spill_stride = spill_stride;
+    stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
+    const unsigned n = *count_ptr;
+    if (ray_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter, (unsigned long long)n);
+    for (;;) {
+        unsigned base = 0;
+        if (lane_id() == 0) base = atomicAdd(head, YK_WAVE);
+        base = __shfl(base, 0);
+        if (base >= n) break;
+        unsigned i = base + lane_id();
+        if (i < n) {
+            float4 ro = rayO[i], rd = rayD[i];
+            float tm = t_max_opt ? t_max_opt[i] : __builtin_inff();
+            int tri;
+            TriHit h = TriHit{0.0f, 0.0f, 0.0f, 0.0f};
+            unsigned nt = 0, nh = 0, st = 0;
+            traverse_closest<BLOCK, LDS_DEPTH, STATS>(sc, f4_xyz(ro), f4_xyz(rd), tm, stk, tri, h, nt, nh, st, ctrl + YK_CTRL_ERR);
+            hit_tri[i] = tri;
+            if (hit_out) hit_out[i] = make_float4(h.t, h.b0, h.b1, h.b2);
+            if (STATS) stats_out[i] = make_uint4(nt, nh, st, 0u);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------ launchers
+#ifndef TRACE_BLOCK
+#define TRACE_BLOCK 256
+#endif
+#ifndef TRACE_LDS
+#define TRACE_LDS 16
+#endif
+#ifndef TRACE_PF_MIN
+#define TRACE_PF_MIN 16
+#endif
+#ifndef TRACE_START_MIN
+#define TRACE_START_MIN 8
+#endif
+#ifndef TRACE_LEAF_MIN
+#define TRACE_LEAF_MIN 16
+#endif
+#ifndef TRACE_CHUNK
+#define TRACE_CHUNK 128
+#endif
+
+unsigned trace_block_size() { return TRACE_BLOCK; }
+unsigned trace_spill_depth() { return YK_STACK_CAP - TRACE_LDS; }
+unsigned trace_blocks_per_cu() {
+    unsigned by_lds = (160u * 1024u) / (TRACE_LDS * TRACE_BLOCK * 8u);
+    unsigned by_waves = 2048u / TRACE_BLOCK;
+    return by_lds < by_waves ? by_lds : by_waves;
+}
+
+void launch_trace_closest(hipStream_t s, unsigned grid, const DevScene& sc, const float4* rayO, const float4* rayD, const float* t_max_opt,
+                          const unsigned* count_ptr, unsigned* head, int* hit_tri, float4* hit_out, uint4* stats_out, uint2* spill,
+                          unsigned spill_stride, unsigned* ctrl, unsigned long long* ray_counter) {
+    if (stats_out)
+        hipLaunchKernelGGL((k_trace_closest<TRACE_BLOCK, TRACE_LDS, true>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, rayO, rayD, t_max_opt, count_ptr,
+                           head, hit_tri, hit_out, stats_out, spill, spill_stride, ctrl, ray_counter);
+    else
+        hipLaunchKernelGGL((k_trace_closest_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc,
+                           rayO, rayD, t_max_opt, count_ptr, head, hit_tri, hit_out, spill, spill_stride, ctrl, ray_counter);
+}
+void launch_trace_any(hipStream_t s, unsigned grid, const DevScene& sc, const float4* shO, const float4* shD, const unsigned* slot_of,
+                      const unsigned* count_ptr, unsigned* head, unsigned char* vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
+                      unsigned long long* shadow_counter) {
+    hipLaunchKernelGGL((k_trace_any_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, shO,
+                       shD, slot_of, count_ptr, head, vis, spill, spill_stride, ctrl, shadow_counter);
+}
+
+}  // namespace yk
