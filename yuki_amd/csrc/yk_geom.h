@@ -51,15 +51,19 @@ YK_HD bool tri_intersect(V3 o, const RayTri& rt, float t_max, V3 p0, V3 p1, V3 p
         e1 = (float)e1d;
         e2 = (float)e2d;
     }
-    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+    // the three rejection tests of triangle.rs:108-131 evaluated without
+    // short-circuit branches (same predicates, straight-line v_cmp + s_and/s_or)
+    const bool any_neg = (e0 < 0.0f) | (e1 < 0.0f) | (e2 < 0.0f);
+    const bool any_pos = (e0 > 0.0f) | (e1 > 0.0f) | (e2 > 0.0f);
     float det = e0 + e1 + e2;
-    if (det == 0.0f) return false;
     float p0z = p0t.z * rt.sz;
     float p1z = p1t.z * rt.sz;
     float p2z = p2t.z * rt.sz;
     float t_scaled = e0 * p0z + e1 * p1z + e2 * p2z;
-    if ((det < 0.0f && (t_scaled >= 0.0f || t_scaled < t_max * det)) || (det > 0.0f && (t_scaled <= 0.0f || t_scaled > t_max * det)))
-        return false;
+    const float td = t_max * det;
+    const bool out_neg = (det < 0.0f) & ((t_scaled >= 0.0f) | (t_scaled < td));
+    const bool out_pos = (det > 0.0f) & ((t_scaled <= 0.0f) | (t_scaled > td));
+    if ((any_neg & any_pos) | (det == 0.0f) | out_neg | out_pos) return false;
     float inv_det = 1.0f / det;
     h.b0 = e0 * inv_det;
     h.b1 = e1 * inv_det;

@@ -24,20 +24,30 @@ namespace yk {
 // a per-thread slice of HBM scratch.  Capacity 64 like the reference (bvh.rs:172).
 #define YK_STACK_CAP 64
 
+// LDS words are addressed through an address_space(3) pointer so the compiler
+// emits ds_read_b64 / ds_write_b64 (a generic pointer in a struct degrades to
+// flat_load/flat_store, which also ties the access to vmcnt).
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(1))) unsigned long long glb_u64;
+
 template <int BLOCK, int LDS_DEPTH> struct TravStack {
-    uint2* lds;      // [LDS_DEPTH][BLOCK]
-    uint2* spill;    // [YK_STACK_CAP - LDS_DEPTH][spill_stride]
+    lds_u64* lds;    // [LDS_DEPTH][BLOCK], entry = ref | tmin_bits << 32
+    glb_u64* spill;  // [YK_STACK_CAP - LDS_DEPTH][spill_stride]
     unsigned spill_stride, gtid;
     __device__ __forceinline__ void push(int sp, unsigned ref, float tmin) {
-        uint2 e = make_uint2(ref, __float_as_uint(tmin));
+        unsigned long long e = (unsigned long long)ref | ((unsigned long long)__float_as_uint(tmin) << 32);
         if (sp < LDS_DEPTH)
             lds[sp * BLOCK + threadIdx.x] = e;
         else
             spill[(size_t)(sp - LDS_DEPTH) * spill_stride + gtid] = e;
     }
     __device__ __forceinline__ uint2 at(int sp) const {
-        if (sp < LDS_DEPTH) return lds[sp * BLOCK + threadIdx.x];
-        return spill[(size_t)(sp - LDS_DEPTH) * spill_stride + gtid];
+        unsigned long long e;
+        if (sp < LDS_DEPTH)
+            e = lds[sp * BLOCK + threadIdx.x];
+        else
+            e = spill[(size_t)(sp - LDS_DEPTH) * spill_stride + gtid];
+        return make_uint2((unsigned)e, (unsigned)(e >> 32));
     }
 };
 
@@ -222,10 +232,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest_pt(DevScene sc, const f
                                                             const float* __restrict__ t_max_opt, const unsigned* count_ptr, unsigned* head,
                                                             int* __restrict__ hit_tri, float4* __restrict__ hit_out, uint2* spill,
                                                             unsigned spill_stride, unsigned* ctrl, unsigned long long* ray_counter) {
-    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    __shared__ unsigned long long lds_stack[LDS_DEPTH * BLOCK];
     TravStack<BLOCK, LDS_DEPTH> stk;
-    stk.lds = lds_stack;
-    stk.spill = spill;
+    stk.lds = (lds_u64*)lds_stack;
+    stk.spill = (glb_u64*)spill;
     stk.spill_stride = spill_stride;
     stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
     const unsigned n = *count_ptr;
@@ -346,10 +356,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace_any_pt(DevScene sc, const float
                                                         const unsigned* __restrict__ slot_of, const unsigned* count_ptr, unsigned* head,
                                                         unsigned char* __restrict__ vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
                                                         unsigned long long* shadow_counter) {
-    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    __shared__ unsigned long long lds_stack[LDS_DEPTH * BLOCK];
     TravStack<BLOCK, LDS_DEPTH> stk;
-    stk.lds = lds_stack;
-    stk.spill = spill;
+    stk.lds = (lds_u64*)lds_stack;
+    stk.spill = (glb_u64*)spill;
     stk.spill_stride = spill_stride;
     stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
     const unsigned n = *count_ptr;
@@ -473,10 +483,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(DevScene sc, const floa
                                                          const unsigned* count_ptr, unsigned* head, int* hit_tri, float4* hit_out,
                                                          uint4* stats_out, uint2* spill, unsigned spill_stride, unsigned* ctrl,
                                                          unsigned long long* ray_counter) {
-    __shared__ uint2 lds_stack[LDS_DEPTH * BLOCK];
+    __shared__ unsigned long long lds_stack[LDS_DEPTH * BLOCK];
     TravStack<BLOCK, LDS_DEPTH> stk;
-    stk.lds = lds_stack;
-    stk.spill = spill;
+    stk.lds = (lds_u64*)lds_stack;
+    stk.spill = (glb_u64*)spill;
     stk.spill_stride = spill_stride;
     stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
     const unsigned n = *count_ptr;
