@@ -145,8 +145,9 @@ def main():
     def step():
         st = it.render_tiles_device(scene, cam, sampler, my_tiles, slab.data_ptr(), want_stats=True)  # syncs the render stream
         if world > 1:
-            dist.gather(slab, gathered, dst=0)
+            dist.gather(slab, gathered, dst=0)  # RCCL, enqueued on torch's stream
             if rank == 0:
+                torch.cuda.current_stream().synchronize()  # the scatter below runs on the library's own stream
                 for r in range(world):
                     tr = ydist.shard_tiles(tiles, r, world)
                     yk.check(yk.lib().yk_film_update_tiles_device(ctx.h, tr.ctypes.data_as(ctypes.c_void_p), len(tr), ctypes.c_void_p(gathered[r].data_ptr()),

@@ -205,19 +205,25 @@ struct ChunkCursor {
     }
     // hands `want` lanes consecutive indices; returns the index of this lane or
     // 0xffffffff.  All lanes of the wave call it (converged).
+    // The chunk shrinks for short queues (late bounces, small per-GPU shares) so that
+    // the rays spread over all resident waves instead of a few waves running
+    // several rounds: chunk = clamp(n / waves_in_grid, 8, CHUNK).
     template <int CHUNK> __device__ __forceinline__ unsigned take(bool want, unsigned n, unsigned* head) {
         unsigned long long mask = __ballot(want);
         if (mask == 0ull || exhausted) return 0xffffffffu;
         if (cur >= end) {
+            const unsigned waves = gridDim.x * (blockDim.x / YK_WAVE);
+            unsigned chunk = n / waves;
+            chunk = chunk < 8u ? 8u : (chunk > (unsigned)CHUNK ? (unsigned)CHUNK : chunk);
             unsigned base = 0;
-            if (lane_id() == 0) base = atomicAdd(head, (unsigned)CHUNK);
+            if (lane_id() == 0) base = atomicAdd(head, chunk);
             base = __shfl(base, 0);
             if (base >= n) {
                 exhausted = true;
                 return 0xffffffffu;
             }
             cur = base;
-            end = base + (unsigned)CHUNK < n ? base + (unsigned)CHUNK : n;
+            end = base + chunk < n ? base + chunk : n;
         }
         unsigned rank = (unsigned)__popcll(mask & ((1ull << lane_id()) - 1ull));
         unsigned idx = cur + rank;
