@@ -88,7 +88,7 @@ def _random_rays(sd, n, seed):
     return o, d.astype(np.float32)
 
 
-@pytest.mark.parametrize("name", ["cornell-tris", "city-small", "cfg2"])
+@pytest.mark.parametrize("name", ["cornell", "cornell-tris", "city-small", "cfg2"])
 def test_trace_closest_bit_exact(ctx, yk, oracle, name):
     sd = scenes.by_name(name)
     sc = yk.Scene(ctx, sd)
@@ -111,7 +111,7 @@ def test_trace_closest_bit_exact(ctx, yk, oracle, name):
     assert np.array_equal(got["shape"], want["shape"])
 
 
-@pytest.mark.parametrize("name", ["cornell-tris", "city-small"])
+@pytest.mark.parametrize("name", ["cornell", "cornell-tris", "city-small"])
 def test_trace_any_bit_exact(ctx, yk, oracle, name):
     sd = scenes.by_name(name)
     sc = yk.Scene(ctx, sd)

@@ -67,7 +67,7 @@ struct yk_scene {
     uint32_t n_triangles = 0, n_spheres = 0, n_lights = 0;
     yk_scene_info info;
     // device
-    DevBuf nodes, tris, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights;
+    DevBuf nodes, tris, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights, spheres;
     DevScene dev;
     bool on_device = false;
 };
@@ -317,13 +317,14 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
             return fail(ctx, YK_ERR_INVALID_ARGUMENT, "material index out of range");
         if (d->tri_area_light && d->tri_area_light[i] >= (int32_t)d->n_lights) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "light index out of range");
     }
+    for (uint32_t k = 0; k < d->n_spheres; ++k)
+        if (d->spheres[k].material < 0 || (uint32_t)d->spheres[k].material >= d->n_materials) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "sphere material out of range");
     if (d->n_triangles && (!d->tri_material || d->n_materials == 0 || d->n_meshes == 0))
         return fail(ctx, YK_ERR_INVALID_ARGUMENT, "triangles need materials and meshes");
     for (uint32_t m = 0; m < d->n_meshes; ++m) {
         if (d->meshes[m].has_normals && !d->normals) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "mesh has_normals without a normals array");
         if (d->meshes[m].has_uvs && !d->uvs) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "mesh has_uvs without a uvs array");
     }
-    if (ctx && d->n_spheres) return fail(ctx, YK_ERR_UNSUPPORTED, "spheres are not implemented on the device path");
 
     yk_scene* s = new yk_scene();
     s->ctx = ctx;
@@ -410,11 +411,22 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
             if (n.is_leaf) last[(size_t)n.a + n.count - 1] = 1;
         for (size_t p = 0; p < np; ++p) {
             uint32_t src = s->bvh.shape_order[p];
+            if (src >= d->n_triangles) {  // sphere: only the source index and the flags are read
+                uint32_t none = 0xffffffffu, fl = (last[p] ? YK_PRIM_LAST : 0u) | YK_PRIM_SPHERE;
+                float w0, w1, w2;
+                std::memcpy(&w0, &none, 4);
+                std::memcpy(&w1, &src, 4);
+                std::memcpy(&w2, &fl, 4);
+                tris[3 * p + 0] = make_float4(0.0f, 0.0f, 0.0f, w0);
+                tris[3 * p + 1] = make_float4(0.0f, 0.0f, 0.0f, w1);
+                tris[3 * p + 2] = make_float4(0.0f, 0.0f, 0.0f, w2);
+                continue;
+            }
             const float* p0 = d->points + 3 * (size_t)d->indices[3 * src];
             const float* p1 = d->points + 3 * (size_t)d->indices[3 * src + 1];
             const float* p2 = d->points + 3 * (size_t)d->indices[3 * src + 2];
             int al = d->tri_area_light ? d->tri_area_light[src] : -1;
-            uint32_t alb = (uint32_t)al, lastb = last[p];
+            uint32_t alb = (uint32_t)al, lastb = last[p] ? YK_PRIM_LAST : 0u;
             float w0, w1, w2;
             std::memcpy(&w0, &alb, 4);
             std::memcpy(&w1, &src, 4);
@@ -429,6 +441,18 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
                             (d->meshes[m].swaps_handedness ? YK_MESH_SWAPS : 0u);
         std::vector<Material> mats(std::max<uint32_t>(d->n_materials, 1));
         for (uint32_t m = 0; m < d->n_materials; ++m) mats[m] = make_material(d->materials[m]);
+        std::vector<DevSphere> spheres(std::max<uint32_t>(d->n_spheres, 1));
+        for (uint32_t k = 0; k < d->n_spheres; ++k) {
+            DevSphere& o = spheres[k];
+            std::memcpy(o.o2w, d->spheres[k].object_to_world, 64);
+            std::memcpy(o.w2o, d->spheres[k].world_to_object, 64);
+            o.radius = d->spheres[k].radius;
+            o.material = d->spheres[k].material;
+            const float* m = o.o2w;  // Transform::swaps_handedness, transform.rs:85-91
+            float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+            o.swaps_handedness = det < 0.0f ? 1u : 0u;
+            o.pad = 0;
+        }
         std::vector<DevLight> lights(std::max<uint32_t>(d->n_lights, 1));
         for (uint32_t l = 0; l < d->n_lights; ++l) lights[l] = make_light(d->lights[l]);
         std::vector<uint32_t> tri_mesh(d->n_triangles, 0);
@@ -454,10 +478,13 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         UP(mesh_flags, mesh_flags.data(), mesh_flags.size());
         UP(materials, mats.data(), mats.size());
         UP(lights, lights.data(), lights.size());
+        UP(spheres, spheres.data(), spheres.size());
 #undef UP
         DevScene& ds = s->dev;
         ds.nodes = s->nodes.as<DevNode>();
         ds.tris = s->tris.as<float4>();
+        ds.spheres = d->n_spheres ? s->spheres.as<DevSphere>() : nullptr;
+        ds.n_triangles = d->n_triangles;
         ds.root_ref = ref_of(0);
         for (int k = 0; k < 3; ++k) {
             ds.root_bmin[k] = nodes[0].bmin[k];
@@ -478,7 +505,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         s->on_device = true;
         s->info.upload_seconds = now_seconds() - u0;
         DevBuf* all[] = {&s->nodes, &s->tris, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
-                         &s->mesh_flags, &s->materials, &s->lights};
+                         &s->mesh_flags, &s->materials, &s->lights, &s->spheres};
         for (DevBuf* b : all) s->info.device_bytes += b->bytes;
     }
     *out = s;
@@ -489,7 +516,7 @@ void yk_scene_destroy(yk_scene* s) {
     if (!s) return;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
     DevBuf* all[] = {&s->nodes, &s->tris, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
-                     &s->mesh_flags, &s->materials, &s->lights};
+                     &s->mesh_flags, &s->materials, &s->lights, &s->spheres};
     for (DevBuf* b : all) b->release();
     delete s;
 }

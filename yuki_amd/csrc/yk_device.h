@@ -53,6 +53,21 @@ struct DevLight {
     float area;
 };
 
+// Sphere record (shapes/sphere.rs:14-35): object_to_world (matrix + inverse);
+// world_to_object is the same pair swapped.
+struct DevSphere {
+    float o2w[16];
+    float w2o[16];
+    float radius;
+    int material;
+    unsigned swaps_handedness;
+    unsigned pad;
+};
+
+// primitive flag bits in tris[3p+2].w
+#define YK_PRIM_LAST 1u
+#define YK_PRIM_SPHERE 2u
+
 // mesh flag bits
 #define YK_MESH_NORMALS 1u
 #define YK_MESH_UVS 2u
@@ -60,7 +75,9 @@ struct DevLight {
 
 struct DevScene {
     const DevNode* nodes;
-    const float4* tris;  // 3 per primitive in leaf order: (p0, bits(area_light)) (p1, bits(src_tri)) (p2, bits(last_in_leaf))
+    const float4* tris;  // 3 per primitive in leaf order: (p0, bits(area_light)) (p1, bits(source shape)) (p2, bits(YK_PRIM_*))
+    const DevSphere* spheres;  // source shape s >= n_triangles is spheres[s - n_triangles]
+    uint32_t n_triangles;
     uint32_t root_ref;
     float root_bmin[3], root_bmax[3];
     // shading data, indexed by source triangle

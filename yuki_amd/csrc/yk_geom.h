@@ -91,11 +91,76 @@ struct Surface {
     V3 n;       // si.n (geometric, face-forwarded to ns when normals exist)
     V3 ns;      // si.shading.n
     V3 dpdus;   // si.shading.dpdu
+    V3 wo;      // si.wo (== -ray.d for triangles; re-normalised through the transform for spheres)
     int material;
     int area_light;
 };
 
 YK_HD V3 ld3(const float* a, uint32_t i) { return V3{a[3 * i], a[3 * i + 1], a[3 * i + 2]}; }
+
+// Sphere::intersect up to the hit distance, shapes/sphere.rs:38-77.  (orx,ory,orz)/(drx..)
+// receive the object-space ray for the caller that goes on to build the surface.
+YK_HD bool sphere_hit_t(const DevSphere& sp, V3 o, V3 d, float t_max, float& t_out, V3& ro, V3& rd) {
+    ro = xf_point(sp.w2o, o);
+    rd = xf_vector(sp.w2o, d);
+    float a = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z;
+    float b = 2.0f * (rd.x * ro.x + rd.y * ro.y + rd.z * ro.z);
+    float c = ro.x * ro.x + ro.y * ro.y + ro.z * ro.z - sp.radius * sp.radius;
+    float discrim = b * b - 4.0f * a * c;
+    if (discrim < 0.0f) return false;
+    float rdisc = sqrtf(discrim);
+    float q = b < 0.0f ? -0.5f * (b - rdisc) : -0.5f * (b + rdisc);
+    float t0 = q / a;
+    float t1 = c / q;
+    if (t0 > t1) {
+        float tmp = t0;
+        t0 = t1;
+        t1 = tmp;
+    }
+    if (t0 > t_max || t1 <= 0.0f) return false;
+    float t = t0;
+    if (t <= 0.0f) {
+        t = t1;
+        if (t > t_max) return false;
+    }
+    t_out = t;
+    return true;
+}
+
+// Rest of Sphere::intersect (sphere.rs:79-116) + Transform * SurfaceInteraction
+// (interaction.rs:141-164): the world-space surface the integrator sees.
+YK_HD Surface make_surface_sphere(const DevSphere& sp, V3 ro, V3 rd, float t, V3 world_d) {
+    V3 p = ro + rd * t;  // Ray::point
+    p = p * (sp.radius / length(p - V3{0.0f, 0.0f, 0.0f}));
+    if (p.x == 0.0f && p.y == 0.0f) p.x = 1e-5f * sp.radius;
+    // (phi = atan2(p.y, p.x) only feeds the uv the integrator never reads)
+    const float phi_max = 2.0f * YK_PI, theta_min = YK_PI, theta_max = 0.0f;
+    float theta = det_acosf(rclamp(p.z / sp.radius, -1.0f, 1.0f));
+    float z_radius = sqrtf(p.x * p.x + p.y * p.y);
+    float inv_z_radius = 1.0f / z_radius;
+    float cos_phi = p.x * inv_z_radius;
+    float sin_phi = p.y * inv_z_radius;
+    V3 dpdu = V3{-phi_max * p.y, phi_max * p.x, 0.0f};
+    V3 dpdv = V3{p.z * cos_phi, p.z * sin_phi, -sp.radius * det_sinf(theta)} * (theta_max - theta_min);
+    // SurfaceInteraction::new in object space
+    V3 n_obj = normalize(cross(dpdu, dpdv));
+    if (sp.swaps_handedness) n_obj = -n_obj;
+    // &object_to_world * si
+    const float* m = sp.o2w;
+    const float* mi = sp.w2o;  // inverse of object_to_world
+    V3 n = normalize(xf_normal(mi, n_obj));
+    V3 sn = normalize(xf_normal(mi, n_obj));
+    sn = faceforward_n(sn, n);
+    Surface s;
+    s.p = xf_point(m, p);
+    s.n = n;
+    s.dpdus = xf_vector(m, dpdu);
+    s.wo = normalize(xf_vector(m, -world_d));
+    s.ns = faceforward_n(sn, s.n);
+    s.material = sp.material;
+    s.area_light = -1;
+    return s;
+}
 
 YK_HD Surface make_surface(const DevScene& sc, uint32_t tri, const TriHit& h) {
     uint32_t i0 = sc.indices[3 * tri], i1 = sc.indices[3 * tri + 1], i2 = sc.indices[3 * tri + 2];
@@ -151,6 +216,25 @@ YK_HD Surface make_surface(const DevScene& sc, uint32_t tri, const TriHit& h) {
     }
     s.material = sc.tri_material[tri];
     s.area_light = sc.tri_area_light[tri];
+    return s;
+}
+
+// The accepted intersection is recomputed from (ray, shape): same operands, same
+// arithmetic as inside the traversal -> same t and barycentrics.
+YK_HD Surface hit_surface(const DevScene& sc, uint32_t shape, V3 o, V3 d) {
+    if (shape >= sc.n_triangles) {
+        const DevSphere& sp = sc.spheres[shape - sc.n_triangles];
+        V3 ro, rd;
+        float t = 0.0f;
+        sphere_hit_t(sp, o, d, __builtin_inff(), t, ro, rd);
+        return make_surface_sphere(sp, ro, rd, t, d);
+    }
+    uint32_t i0 = sc.indices[3 * shape], i1 = sc.indices[3 * shape + 1], i2 = sc.indices[3 * shape + 2];
+    RayTri rt = ray_tri_setup(d);
+    TriHit th = TriHit{0.0f, 0.0f, 0.0f, 0.0f};
+    tri_intersect(o, rt, __builtin_inff(), ld3(sc.points, i0), ld3(sc.points, i1), ld3(sc.points, i2), th);
+    Surface s = make_surface(sc, shape, th);
+    s.wo = -d;
     return s;
 }
 

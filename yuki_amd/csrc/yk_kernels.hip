@@ -182,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderParams prm, 
         st.rng.inc = 1;
         st.px = st.py = st.sample_index = st.dimension = 0;
         Surface sf;
-        sf.p = sf.n = sf.ns = sf.dpdus = V3{0, 0, 1};
+        sf.p = sf.n = sf.ns = sf.dpdus = sf.wo = V3{0, 0, 1};
         sf.material = 0;
         sf.area_light = -1;
         Material mat;
@@ -211,13 +211,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderParams prm, 
             int tri = hit_tri[i];
             hit = tri >= 0;
             if (hit) {
-                // recompute the accepted intersection: same ray, same triangle, same
-                // arithmetic -> same (t, b0, b1, b2) as inside the traversal
-                uint32_t i0 = sc.indices[3 * tri], i1 = sc.indices[3 * tri + 1], i2 = sc.indices[3 * tri + 2];
-                RayTri rt = ray_tri_setup(d);
-                TriHit th;
-                tri_intersect(o, rt, __builtin_inff(), ld3(sc.points, i0), ld3(sc.points, i1), ld3(sc.points, i2), th);
-                sf = make_surface(sc, (uint32_t)tri, th);
+                sf = hit_surface(sc, (uint32_t)tri, o, d);
                 mat = sc.materials[sf.material];
                 fr = make_frame(sf.n, sf.ns, sf.dpdus);
                 wo = -d;
@@ -236,7 +230,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderParams prm, 
                 sampler_get_2d(prm.sampler, st, ux, uy);
                 LightSample ls = sample_light(sc.lights[l], (int)l, sf.p, ux, uy);
                 if (!is_black(ls.li)) {
-                    RGB f = bsdf_f(mat, fr, wo, ls.l);
+                    RGB f = bsdf_f(mat, fr, sf.wo, ls.l);  // path.rs:105 uses si.wo
                     if (ls.has_vis && !is_black(f)) {
                         contrib = f * ls.li * rclamp(dot_nv(sf.ns, ls.l), 0.0f, 1.0f) / ls.pdf;
                         // VisibilityTester::ray = p0.spawn_ray_to(p1), interaction.rs:44-59
@@ -411,11 +405,7 @@ __global__ void k_debug_shade(DevScene sc, uint32_t integrator, PathBuffers cur,
         c = RGB{(float)s.x, (float)s.y, tri >= 0 ? (float)s.y : 0.0f};
     } else if (tri >= 0) {
         V3 o = f4_xyz(cur.rayO[i]), d = f4_xyz(cur.rayD[i]);
-        uint32_t i0 = sc.indices[3 * tri], i1 = sc.indices[3 * tri + 1], i2 = sc.indices[3 * tri + 2];
-        RayTri rt = ray_tri_setup(d);
-        TriHit th;
-        tri_intersect(o, rt, __builtin_inff(), ld3(sc.points, i0), ld3(sc.points, i1), ld3(sc.points, i2), th);
-        Surface sf = make_surface(sc, (uint32_t)tri, th);
+        Surface sf = hit_surface(sc, (uint32_t)tri, o, d);
         V3 nn = integrator == YK_INTEGRATOR_GEOMETRY_NORMALS ? sf.n : sf.ns;
         c = RGB{nn.x, nn.y, nn.z} / 2.0f + 0.5f;
     }

@@ -123,14 +123,22 @@ __device__ __forceinline__ void traverse_closest(const DevScene& sc, V3 o, V3 d,
             unsigned prim = cur & ~YK_LEAF_BIT;
             for (;;) {
                 float4 v0 = sc.tris[3 * prim], v1 = sc.tris[3 * prim + 1], v2 = sc.tris[3 * prim + 2];
-                TriHit h;
+                const unsigned pflags = __float_as_uint(v2.w);
+                TriHit h = TriHit{0.0f, 0.0f, 0.0f, 0.0f};
                 if (STATS) shape_tests += 1;
-                if (tri_intersect(o, rt, t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h)) {
+                bool got;
+                if (pflags & YK_PRIM_SPHERE) {
+                    V3 ro, rd;
+                    got = sphere_hit_t(sc.spheres[__float_as_uint(v1.w) - sc.n_triangles], o, d, t_max, h.t, ro, rd);
+                } else {
+                    got = tri_intersect(o, rt, t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h);
+                }
+                if (got) {
                     out_hit = h;
                     out_tri = (int)__float_as_uint(v1.w);
                     t_max = h.t;
                 }
-                if (__float_as_uint(v2.w) & 1u) break;
+                if (pflags & YK_PRIM_LAST) break;
                 ++prim;
             }
         }
@@ -168,7 +176,7 @@ __device__ __forceinline__ void traverse_closest(const DevScene& sc, V3 o, V3 d,
 // Per-ray arithmetic and visiting order are exactly those of traverse_closest /
 // traverse_any above.
 struct LaneRay {
-    V3 o, inv;
+    V3 o, inv, d;
     RayTri rt;
     float t_max;
     unsigned negmask;
@@ -176,6 +184,7 @@ struct LaneRay {
 
 __device__ __forceinline__ void lane_ray_setup(LaneRay& r, V3 o, V3 d, float t_max) {
     r.o = o;
+    r.d = d;
     r.inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
     r.negmask = (r.inv.x < 0.0f ? 1u : 0u) | (r.inv.y < 0.0f ? 2u : 0u) | (r.inv.z < 0.0f ? 4u : 0u);
     r.rt = ray_tri_setup(d);
@@ -233,7 +242,7 @@ struct ChunkCursor {
     }
 };
 
-template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int CHUNK>
+template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int CHUNK, bool SPHERES>
 __global__ __launch_bounds__(BLOCK) void k_trace_closest_pt(DevScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
                                                             const float* __restrict__ t_max_opt, const unsigned* count_ptr, unsigned* head,
                                                             int* __restrict__ hit_tri, float4* __restrict__ hit_out, uint2* spill,
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest_pt(DevScene sc, const f
     float pf_t = 0.0f;
     unsigned pf_idx = 0;
     LaneRay r;
-    r.o = r.inv = V3{0, 0, 0};
+    r.o = r.inv = r.d = V3{0, 0, 0};
     r.rt = RayTri{0, 1, 2, 0, 0, 0};
     r.t_max = 0.0f;
     r.negmask = 0;
@@ -337,13 +346,21 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest_pt(DevScene sc, const f
             unsigned prim = cur & ~YK_LEAF_BIT;
             for (;;) {
                 float4 v0 = sc.tris[3 * prim], v1 = sc.tris[3 * prim + 1], v2 = sc.tris[3 * prim + 2];
-                TriHit h;
-                if (tri_intersect(r.o, r.rt, r.t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h)) {
+                const unsigned pflags = __float_as_uint(v2.w);
+                TriHit h = TriHit{0.0f, 0.0f, 0.0f, 0.0f};
+                bool got;
+                if (SPHERES && (pflags & YK_PRIM_SPHERE)) {
+                    V3 ro, rd;
+                    got = sphere_hit_t(sc.spheres[__float_as_uint(v1.w) - sc.n_triangles], r.o, r.d, r.t_max, h.t, ro, rd);
+                } else {
+                    got = tri_intersect(r.o, r.rt, r.t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h);
+                }
+                if (got) {
                     best_hit = h;
                     best = (int)__float_as_uint(v1.w);
                     r.t_max = h.t;
                 }
-                if (__float_as_uint(v2.w) & 1u) break;
+                if (pflags & YK_PRIM_LAST) break;
                 ++prim;
             }
             if (!pop_closest(stk, sp, r.t_max, cur)) {
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest_pt(DevScene sc, const f
 
 // Shadow rays: shO/shD are dense (compacted by `shade`); slot_of[k] is where the
 // verdict goes (vis[slot] = 2 when occluded); slot_of == NULL (API mode): vis[k] = 0/1.
-template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int CHUNK>
+template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int CHUNK, bool SPHERES>
 __global__ __launch_bounds__(BLOCK) void k_trace_any_pt(DevScene sc, const float4* __restrict__ shO, const float4* __restrict__ shD,
                                                         const unsigned* __restrict__ slot_of, const unsigned* count_ptr, unsigned* head,
                                                         unsigned char* __restrict__ vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
@@ -378,7 +395,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_any_pt(DevScene sc, const float
     float4 pf_o = make_float4(0, 0, 0, 0), pf_d = make_float4(0, 0, 1, 0);
     unsigned pf_slot = 0;
     LaneRay r;
-    r.o = r.inv = V3{0, 0, 0};
+    r.o = r.inv = r.d = V3{0, 0, 0};
     r.rt = RayTri{0, 1, 2, 0, 0, 0};
     r.t_max = 0.0f;
     r.negmask = 0;
@@ -456,16 +473,25 @@ __global__ __launch_bounds__(BLOCK) void k_trace_any_pt(DevScene sc, const float
             bool occluded = false;
             for (;;) {
                 float4 v0 = sc.tris[3 * prim], v1 = sc.tris[3 * prim + 1], v2 = sc.tris[3 * prim + 2];
+                const unsigned pflags = __float_as_uint(v2.w);
                 TriHit h;
-                if (tri_intersect(r.o, r.rt, r.t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h)) {
+                bool got;
+                if (SPHERES && (pflags & YK_PRIM_SPHERE)) {
+                    V3 ro, rd;
+                    got = sphere_hit_t(sc.spheres[__float_as_uint(v1.w) - sc.n_triangles], r.o, r.d, r.t_max, h.t, ro, rd);
+                } else {
+                    got = tri_intersect(r.o, r.rt, r.t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h);
+                }
+                if (got) {
                     // bvh.rs:269-280: a hit on the sampled area light's own surface does not occlude
+                    // (spheres carry no area light: v0.w = -1)
                     int prim_light = (int)__float_as_uint(v0.w);
                     if (!(area_light >= 0 && prim_light >= 0 && prim_light == area_light)) {
                         occluded = true;
                         break;
                     }
                 }
-                if (__float_as_uint(v2.w) & 1u) break;
+                if (pflags & YK_PRIM_LAST) break;
                 ++prim;
             }
             if (occluded) {
@@ -552,15 +578,22 @@ void launch_trace_closest(hipStream_t s, unsigned grid, const DevScene& sc, cons
     if (stats_out)
         hipLaunchKernelGGL((k_trace_closest<TRACE_BLOCK, TRACE_LDS, true>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, rayO, rayD, t_max_opt, count_ptr,
                            head, hit_tri, hit_out, stats_out, spill, spill_stride, ctrl, ray_counter);
+    else if (sc.spheres)
+        hipLaunchKernelGGL((k_trace_closest_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, true>), dim3(grid),
+                           dim3(TRACE_BLOCK), 0, s, sc, rayO, rayD, t_max_opt, count_ptr, head, hit_tri, hit_out, spill, spill_stride, ctrl, ray_counter);
     else
-        hipLaunchKernelGGL((k_trace_closest_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc,
-                           rayO, rayD, t_max_opt, count_ptr, head, hit_tri, hit_out, spill, spill_stride, ctrl, ray_counter);
+        hipLaunchKernelGGL((k_trace_closest_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, false>), dim3(grid),
+                           dim3(TRACE_BLOCK), 0, s, sc, rayO, rayD, t_max_opt, count_ptr, head, hit_tri, hit_out, spill, spill_stride, ctrl, ray_counter);
 }
 void launch_trace_any(hipStream_t s, unsigned grid, const DevScene& sc, const float4* shO, const float4* shD, const unsigned* slot_of,
                       const unsigned* count_ptr, unsigned* head, unsigned char* vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
                       unsigned long long* shadow_counter) {
-    hipLaunchKernelGGL((k_trace_any_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, shO,
-                       shD, slot_of, count_ptr, head, vis, spill, spill_stride, ctrl, shadow_counter);
+    if (sc.spheres)
+        hipLaunchKernelGGL((k_trace_any_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, true>), dim3(grid), dim3(TRACE_BLOCK), 0,
+                           s, sc, shO, shD, slot_of, count_ptr, head, vis, spill, spill_stride, ctrl, shadow_counter);
+    else
+        hipLaunchKernelGGL((k_trace_any_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, false>), dim3(grid), dim3(TRACE_BLOCK), 0,
+                           s, sc, shO, shD, slot_of, count_ptr, head, vis, spill, spill_stride, ctrl, shadow_counter);
 }
 
 }  // namespace yk
