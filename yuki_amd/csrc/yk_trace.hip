@@ -16,6 +16,17 @@
 #include "yk_kernels.h"
 #include "yk_wave.h"
 
+// build-time tuning knobs of the persistent traversal kernels
+#ifndef TRACE_BLOCK
+#define TRACE_BLOCK 256
+#endif
+#ifndef TRACE_LDS
+#define TRACE_LDS 12  // stack entries per lane kept in LDS
+#endif
+#ifndef TRACE_MIN_WAVES
+#define TRACE_MIN_WAVES 6  // waves per SIMD the register allocator must leave room for
+#endif
+
 namespace yk {
 
 // ------------------------------------------------------------------ traversal
@@ -242,8 +253,8 @@ struct ChunkCursor {
     }
 };
 
-template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int CHUNK, bool SPHERES>
-__global__ __launch_bounds__(BLOCK) void k_trace_closest_pt(DevScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
+template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int CHUNK, bool SPHERES, bool API>
+__global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(DevScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
                                                             const float* __restrict__ t_max_opt, const unsigned* count_ptr, unsigned* head,
                                                             int* __restrict__ hit_tri, float4* __restrict__ hit_out, uint2* spill,
                                                             unsigned spill_stride, unsigned* ctrl, unsigned long long* ray_counter) {
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest_pt(DevScene sc, const f
         const bool go = (unsigned)__popcll(__ballot(startable)) >= (unsigned)START_MIN || !__any(active);
         if (go && startable) {
             pf_valid = false;
-            lane_ray_setup(r, f4_xyz(pf_o), f4_xyz(pf_d), pf_t);
+            lane_ray_setup(r, f4_xyz(pf_o), f4_xyz(pf_d), API ? pf_t : __builtin_inff());
             ray_i = pf_idx;
             float tmin;
             if (slab(root_lo, root_hi, r.o, r.inv, r.t_max, tmin)) {
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest_pt(DevScene sc, const f
                 if (idx != 0xffffffffu) {
                     pf_o = rayO[idx];
                     pf_d = rayD[idx];
-                    pf_t = t_max_opt ? t_max_opt[idx] : __builtin_inff();
+                    pf_t = (API && t_max_opt) ? t_max_opt[idx] : __builtin_inff();
                     pf_idx = idx;
                     pf_valid = true;
                 }
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest_pt(DevScene sc, const f
                     cur = far_ref;  // no intervening leaf can shrink t_max: the test result is final
                 } else if (!pop_closest(stk, sp, r.t_max, cur)) {
                     hit_tri[ray_i] = best;
-                    if (hit_out) hit_out[ray_i] = make_float4(best_hit.t, best_hit.b0, best_hit.b1, best_hit.b2);
+                    if (API && hit_out) hit_out[ray_i] = make_float4(best_hit.t, best_hit.b0, best_hit.b1, best_hit.b2);
                     active = false;
                 }
             }
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest_pt(DevScene sc, const f
                     got = tri_intersect(r.o, r.rt, r.t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h);
                 }
                 if (got) {
-                    best_hit = h;
+                    if (API) best_hit = h;
                     best = (int)__float_as_uint(v1.w);
                     r.t_max = h.t;
                 }
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest_pt(DevScene sc, const f
             }
             if (!pop_closest(stk, sp, r.t_max, cur)) {
                 hit_tri[ray_i] = best;
-                if (hit_out) hit_out[ray_i] = make_float4(best_hit.t, best_hit.b0, best_hit.b1, best_hit.b2);
+                if (API && hit_out) hit_out[ray_i] = make_float4(best_hit.t, best_hit.b0, best_hit.b1, best_hit.b2);
                 active = false;
             }
         }
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest_pt(DevScene sc, const f
 // Shadow rays: shO/shD are dense (compacted by `shade`); slot_of[k] is where the
 // verdict goes (vis[slot] = 2 when occluded); slot_of == NULL (API mode): vis[k] = 0/1.
 template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int CHUNK, bool SPHERES>
-__global__ __launch_bounds__(BLOCK) void k_trace_any_pt(DevScene sc, const float4* __restrict__ shO, const float4* __restrict__ shD,
+__global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScene sc, const float4* __restrict__ shO, const float4* __restrict__ shD,
                                                         const unsigned* __restrict__ slot_of, const unsigned* count_ptr, unsigned* head,
                                                         unsigned char* __restrict__ vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
                                                         unsigned long long* shadow_counter) {
@@ -545,12 +556,6 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(DevScene sc, const floa
 
 
 // ------------------------------------------------------------------ launchers
-#ifndef TRACE_BLOCK
-#define TRACE_BLOCK 256
-#endif
-#ifndef TRACE_LDS
-#define TRACE_LDS 16
-#endif
 #ifndef TRACE_PF_MIN
 #define TRACE_PF_MIN 16
 #endif
@@ -568,7 +573,7 @@ unsigned trace_block_size() { return TRACE_BLOCK; }
 unsigned trace_spill_depth() { return YK_STACK_CAP - TRACE_LDS; }
 unsigned trace_blocks_per_cu() {
     unsigned by_lds = (160u * 1024u) / (TRACE_LDS * TRACE_BLOCK * 8u);
-    unsigned by_waves = 2048u / TRACE_BLOCK;
+    unsigned by_waves = (unsigned)TRACE_MIN_WAVES * 256u / TRACE_BLOCK;
     return by_lds < by_waves ? by_lds : by_waves;
 }
 
@@ -578,12 +583,18 @@ void launch_trace_closest(hipStream_t s, unsigned grid, const DevScene& sc, cons
     if (stats_out)
         hipLaunchKernelGGL((k_trace_closest<TRACE_BLOCK, TRACE_LDS, true>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, rayO, rayD, t_max_opt, count_ptr,
                            head, hit_tri, hit_out, stats_out, spill, spill_stride, ctrl, ray_counter);
-    else if (sc.spheres)
-        hipLaunchKernelGGL((k_trace_closest_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, true>), dim3(grid),
-                           dim3(TRACE_BLOCK), 0, s, sc, rayO, rayD, t_max_opt, count_ptr, head, hit_tri, hit_out, spill, spill_stride, ctrl, ray_counter);
-    else
-        hipLaunchKernelGGL((k_trace_closest_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, false>), dim3(grid),
-                           dim3(TRACE_BLOCK), 0, s, sc, rayO, rayD, t_max_opt, count_ptr, head, hit_tri, hit_out, spill, spill_stride, ctrl, ray_counter);
+    else {
+        const bool api = t_max_opt != nullptr || hit_out != nullptr;
+#define YK_LAUNCH_CLOSEST(SPH, API)                                                                                                              \
+    hipLaunchKernelGGL((k_trace_closest_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, SPH, API>), dim3(grid), \
+                       dim3(TRACE_BLOCK), 0, s, sc, rayO, rayD, t_max_opt, count_ptr, head, hit_tri, hit_out, spill, spill_stride, ctrl, ray_counter)
+        if (sc.spheres) {
+            if (api) YK_LAUNCH_CLOSEST(true, true); else YK_LAUNCH_CLOSEST(true, false);
+        } else {
+            if (api) YK_LAUNCH_CLOSEST(false, true); else YK_LAUNCH_CLOSEST(false, false);
+        }
+#undef YK_LAUNCH_CLOSEST
+    }
 }
 void launch_trace_any(hipStream_t s, unsigned grid, const DevScene& sc, const float4* shO, const float4* shD, const unsigned* slot_of,
                       const unsigned* count_ptr, unsigned* head, unsigned char* vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
