@@ -135,16 +135,17 @@ def test_many_tiles_per_block_is_deterministic(yk):
     sampler = yk.SamplerType.Stratified((2, 2), True, SEED)
     integ = yk.IntegratorType.Path(yk.PathParams(max_depth=8))
     outs = []
-    for batch in (16 << 20, 1 << 20):
-        c = yk.Context(0, batch_paths=batch)
+    for batch, streams in ((16 << 20, 1), (1 << 20, 1), (16 << 20, 2), (3 << 20, 2)):
+        c = yk.Context(0, batch_paths=batch, streams=streams)
         sc = yk.Scene(c, sd)
         out, st = yk.IntegratorType.instantiate(c, integ).render_tiles(sc, yk.Camera(sd.camera, fs), sampler, yk.film_tiles(fs))
         outs.append((out, st.rays, st.shadow_rays, st.batches))
         sc.close()
         c.close()
-    assert outs[0][3] == 1 and outs[1][3] == 8
-    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
-    assert np.array_equal(_bits(outs[0][0]), _bits(outs[1][0]))
+    assert [o[3] for o in outs] == [1, 8, 2, 3]  # one batch; eight; two halves on two streams; three alternating
+    for o in outs[1:]:
+        assert o[1] == outs[0][1] and o[2] == outs[0][2]
+        assert np.array_equal(_bits(o[0]), _bits(outs[0][0]))
     assert np.isfinite(outs[0][0]).all()
 
 

@@ -53,13 +53,21 @@ struct yk_context {
     int64_t batch_paths = 128 << 20;
     int64_t sample_buf_cap = (int64_t)64 << 30;
     int64_t time_kernels = 1;
-    // work buffers
-    DevBuf path[2][4];
-    DevBuf hit, pend, shO, shD, shC, vis, shq, ctrl, spill, sample_buf, pixel_xy, tiles, tile_off, counters, stats4, hit4, scratch[8];
-    size_t cap_paths = 0;
-    unsigned cap_lights = 0;
+    int64_t streams = 2;  // batches in flight (1 or 2): the second stream's launches fill the first one's tails
+    // per-stream work buffers
+    struct WorkSet {
+        DevBuf path[2][4];
+        DevBuf hit, pend, shO, shD, shC, vis, shq, ctrl, spill;
+        size_t cap_paths = 0;
+        unsigned cap_lights = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+    } ws[2];
+    DevBuf sample_buf, pixel_xy, tiles, tile_off, counters, stats4, hit4, scratch[8];
     std::vector<hipEvent_t> ev_pool;
 };
+
+typedef yk_context::WorkSet WorkSet;
 
 struct yk_scene {
     yk_context* ctx = nullptr;
@@ -127,10 +135,14 @@ yk_status yk_context_create(int device, yk_context** out) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->ws[1].stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ws[0].done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ws[1].done, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return YK_ERR_DEVICE;
     }
+    ctx->ws[0].stream = ctx->stream;
     *out = ctx;
     return YK_OK;
 }
@@ -139,10 +151,16 @@ void yk_context_destroy(yk_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 4; ++b) ctx->path[a][b].release();
-    DevBuf* all[] = {&ctx->hit, &ctx->pend, &ctx->shO, &ctx->shD, &ctx->shC, &ctx->vis, &ctx->shq, &ctx->ctrl, &ctx->spill, &ctx->sample_buf,
-                     &ctx->pixel_xy, &ctx->tiles, &ctx->tile_off, &ctx->counters, &ctx->stats4, &ctx->hit4};
+    (void)hipStreamSynchronize(ctx->ws[1].stream);
+    for (WorkSet& w : ctx->ws) {
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 4; ++b) w.path[a][b].release();
+        DevBuf* wb[] = {&w.hit, &w.pend, &w.shO, &w.shD, &w.shC, &w.vis, &w.shq, &w.ctrl, &w.spill};
+        for (DevBuf* b : wb) b->release();
+        if (w.done) (void)hipEventDestroy(w.done);
+    }
+    (void)hipStreamDestroy(ctx->ws[1].stream);
+    DevBuf* all[] = {&ctx->sample_buf, &ctx->pixel_xy, &ctx->tiles, &ctx->tile_off, &ctx->counters, &ctx->stats4, &ctx->hit4};
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : ctx->scratch) b.release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -165,6 +183,9 @@ yk_status yk_context_set_option(yk_context* ctx, const char* key, int64_t value)
     } else if (k == "sample_buf_cap") {
         if (value < (1 << 20)) return YK_ERR_INVALID_ARGUMENT;
         ctx->sample_buf_cap = value;
+    } else if (k == "streams") {
+        if (value < 1 || value > 2) return YK_ERR_INVALID_ARGUMENT;
+        ctx->streams = value;
     } else if (k == "time_kernels") {
         ctx->time_kernels = value;
     } else {
@@ -535,41 +556,41 @@ yk_status yk_scene_export_bvh(const yk_scene* s, yk_bvh_node* nodes, uint32_t* s
 }
 
 // ------------------------------------------------------------------ render
-static yk_status ensure_work_buffers(yk_context* ctx, size_t paths, unsigned n_lights) {
+static yk_status ensure_work_buffers(yk_context* ctx, WorkSet& ws, size_t paths, unsigned n_lights) {
     unsigned nl = std::max(1u, n_lights);
-    if (paths <= ctx->cap_paths && nl <= ctx->cap_lights) return YK_OK;
-    paths = std::max(paths, ctx->cap_paths);
-    nl = std::max(nl, ctx->cap_lights);
+    if (paths <= ws.cap_paths && nl <= ws.cap_lights) return YK_OK;
+    paths = std::max(paths, ws.cap_paths);
+    nl = std::max(nl, ws.cap_lights);
     for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 4; ++b) HIP_TRY(ctx, ctx->path[a][b].ensure(paths * 16));
-    HIP_TRY(ctx, ctx->hit.ensure(paths * 4));
-    HIP_TRY(ctx, ctx->pend.ensure(paths * 16));
-    HIP_TRY(ctx, ctx->shO.ensure(paths * nl * 16));
-    HIP_TRY(ctx, ctx->shD.ensure(paths * nl * 16));
-    HIP_TRY(ctx, ctx->shC.ensure(paths * nl * 16));
-    HIP_TRY(ctx, ctx->vis.ensure(paths * nl));
-    HIP_TRY(ctx, ctx->shq.ensure(paths * nl * 4));
-    HIP_TRY(ctx, ctx->ctrl.ensure(YK_CTRL_WORDS * 4));
+        for (int b = 0; b < 4; ++b) HIP_TRY(ctx, ws.path[a][b].ensure(paths * 16));
+    HIP_TRY(ctx, ws.hit.ensure(paths * 4));
+    HIP_TRY(ctx, ws.pend.ensure(paths * 16));
+    HIP_TRY(ctx, ws.shO.ensure(paths * nl * 16));
+    HIP_TRY(ctx, ws.shD.ensure(paths * nl * 16));
+    HIP_TRY(ctx, ws.shC.ensure(paths * nl * 16));
+    HIP_TRY(ctx, ws.vis.ensure(paths * nl));
+    HIP_TRY(ctx, ws.shq.ensure(paths * nl * 4));
+    HIP_TRY(ctx, ws.ctrl.ensure(YK_CTRL_WORDS * 4));
     HIP_TRY(ctx, ctx->counters.ensure(64));
-    ctx->cap_paths = paths;
-    ctx->cap_lights = nl;
+    ws.cap_paths = paths;
+    ws.cap_lights = nl;
     return YK_OK;
 }
 
 static unsigned trace_grid(const yk_context* ctx) { return (unsigned)ctx->n_cu * trace_blocks_per_cu(); }
 
-static yk_status ensure_spill(yk_context* ctx) {
+static yk_status ensure_spill(yk_context* ctx, WorkSet& ws) {
     size_t threads = (size_t)trace_grid(ctx) * trace_block_size();
-    HIP_TRY(ctx, ctx->spill.ensure(threads * trace_spill_depth() * 8));
+    HIP_TRY(ctx, ws.spill.ensure(threads * trace_spill_depth() * 8));
     return YK_OK;
 }
 
-static PathBuffers path_buffers(yk_context* ctx, int which) {
+static PathBuffers path_buffers(WorkSet& ws, int which) {
     PathBuffers p;
-    p.rayO = ctx->path[which][0].as<float4>();
-    p.rayD = ctx->path[which][1].as<float4>();
-    p.thru = ctx->path[which][2].as<float4>();
-    p.rngs = ctx->path[which][3].as<uint4>();
+    p.rayO = ws.path[which][0].as<float4>();
+    p.rayD = ws.path[which][1].as<float4>();
+    p.thru = ws.path[which][2].as<float4>();
+    p.rngs = ws.path[which][3].as<uint4>();
     return p;
 }
 
@@ -627,32 +648,32 @@ struct KernelTimer {
 };
 
 // one batch of `n` paths already generated into buffer 0; runs the bounce loop
-static void run_bounces(yk_context* ctx, hipStream_t st, const yk_scene* scene, const RenderParams& prm, const uint32_t* pixel_xy,
+static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* scene, const RenderParams& prm, const uint32_t* pixel_xy,
                         const uint32_t* sample_index_tab, float4* sample_buf, KernelTimer& kt, unsigned long long* counters) {
-    unsigned* ctrl = ctx->ctrl.as<unsigned>();
+    unsigned* ctrl = ws.ctrl.as<unsigned>();
     const DevScene& ds = scene->dev;
     const unsigned tg = trace_grid(ctx);
     const unsigned sg = (unsigned)ctx->n_cu * 8u;
     unsigned cur = 0;
     for (unsigned b = 0; b < prm.max_depth; ++b) {
-        PathBuffers pc = path_buffers(ctx, (int)cur), pn = path_buffers(ctx, (int)(cur ^ 1u));
+        PathBuffers pc = path_buffers(ws, (int)cur), pn = path_buffers(ws, (int)(cur ^ 1u));
         // reset the consumer-side counters of this bounce
         (void)hipMemsetAsync(ctrl + (cur ^ 1u), 0, 4, st);
         (void)hipMemsetAsync(ctrl + YK_CTRL_SHQ, 0, 4, st);
         int e = kt.begin(st);
-        launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, ctrl + cur, ctrl + YK_CTRL_HEADS + 2 * b, ctx->hit.as<int>(), nullptr, nullptr,
-                             ctx->spill.as<uint2>(), tg * trace_block_size(), ctrl, counters);
+        launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, ctrl + cur, ctrl + YK_CTRL_HEADS + 2 * b, ws.hit.as<int>(), nullptr, nullptr,
+                             ws.spill.as<uint2>(), tg * trace_block_size(), ctrl, counters);
         kt.end(e, 0, st);
         e = kt.begin(st);
-        launch_shade(st, sg, ds, prm, pixel_xy, sample_index_tab, pc, pn, ctx->hit.as<int>(), ctx->pend.as<float4>(), ctx->shO.as<float4>(),
-                     ctx->shD.as<float4>(), ctx->shC.as<float4>(), ctx->vis.as<unsigned char>(), ctx->shq.as<unsigned>(), ctrl, cur);
+        launch_shade(st, sg, ds, prm, pixel_xy, sample_index_tab, pc, pn, ws.hit.as<int>(), ws.pend.as<float4>(), ws.shO.as<float4>(),
+                     ws.shD.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ws.shq.as<unsigned>(), ctrl, cur);
         kt.end(e, 2, st);
         e = kt.begin(st);
-        launch_trace_any(st, tg, ds, ctx->shO.as<float4>(), ctx->shD.as<float4>(), ctx->shq.as<unsigned>(), ctrl + YK_CTRL_SHQ,
-                         ctrl + YK_CTRL_HEADS + 2 * b + 1, ctx->vis.as<unsigned char>(), ctx->spill.as<uint2>(), tg * trace_block_size(), ctrl,
+        launch_trace_any(st, tg, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), ctrl + YK_CTRL_SHQ,
+                         ctrl + YK_CTRL_HEADS + 2 * b + 1, ws.vis.as<unsigned char>(), ws.spill.as<uint2>(), tg * trace_block_size(), ctrl,
                          counters + 1);
         kt.end(e, 1, st);
-        launch_accumulate(st, sg, prm, pc, ctx->pend.as<float4>(), ctx->shC.as<float4>(), ctx->vis.as<unsigned char>(), ds.n_lights, sample_buf, ctrl, cur);
+        launch_accumulate(st, sg, prm, pc, ws.pend.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ds.n_lights, sample_buf, ctrl, cur);
         cur ^= 1u;
     }
 }
@@ -690,19 +711,31 @@ yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const y
     std::memcpy(cam.r2c, camera->raster_to_camera, 64);
 
     const bool is_path = prm.integrator == YK_INTEGRATOR_PATH;
-    size_t batch = (size_t)std::min<uint64_t>((uint64_t)ctx->batch_paths, total_px * spp);
+    // Work is cut into batches of <= batch_paths camera samples.  With streams == 2
+    // batches alternate between two work sets / HIP streams, so the latency-bound
+    // tail launches of one batch (late bounces, few rays) run beside the bulk
+    // launches of the other.  A job that fits one batch is split in two halves.
+    const uint64_t total_work = total_px * spp;
+    // (a job that fills the GPU as ONE batch gains nothing from the split — measured —
+    // and keeps per-kernel timings unambiguous, so it stays on one stream)
+    size_t batch = (size_t)std::min<uint64_t>((uint64_t)ctx->batch_paths, total_work);
+    const bool small_job = total_work >= (1u << 21) && total_work < (48u << 20);
+    const int n_ws = (ctx->streams >= 2 && is_path && !stream && (total_work > batch || small_job)) ? 2 : 1;
+    if (n_ws == 2 && batch * 2 > total_work) batch = (size_t)((total_work + 1) / 2);
     {
         // keep the per-batch work buffers (148 + 53*n_lights bytes per path) within half of the free HBM
         size_t free_b = 0, total_b = 0;
-        if (batch > ctx->cap_paths && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t per_path = 148 + 53 * (size_t)std::max(1u, scene->n_lights);
+        if (batch > ctx->ws[0].cap_paths && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t per_path = (148 + 53 * (size_t)std::max(1u, scene->n_lights)) * (size_t)n_ws;
             const size_t fit = (free_b / 2) / per_path;
             if (fit >= 65536 && batch > fit) batch = fit;
         }
     }
-    yk_status wb = ensure_work_buffers(ctx, batch, scene->n_lights);
-    if (wb != YK_OK) return wb;
-    if ((wb = ensure_spill(ctx)) != YK_OK) return wb;
+    for (int w = 0; w < n_ws; ++w) {
+        yk_status wb = ensure_work_buffers(ctx, ctx->ws[w], batch, scene->n_lights);
+        if (wb != YK_OK) return wb;
+        if ((wb = ensure_spill(ctx, ctx->ws[w])) != YK_OK) return wb;
+    }
     HIP_TRY(ctx, ctx->tiles.ensure(n_tiles * sizeof(yk_tile)));
     HIP_TRY(ctx, ctx->tile_off.ensure((n_tiles + 1) * 4));
     if (!is_path && prm.integrator == YK_INTEGRATOR_BVH_INTERSECTIONS) HIP_TRY(ctx, ctx->stats4.ensure(batch * 16));
@@ -719,7 +752,6 @@ yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const y
         HIP_TRY(ctx, hipEventRecord(ev0, st));
     }
     uint32_t n_batches = 0, n_trace = 0;
-    unsigned* ctrl = ctx->ctrl.as<unsigned>();
     float* out = reinterpret_cast<float*>(d_out_rgb);
 
     size_t t_begin = 0;
@@ -738,33 +770,48 @@ yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const y
         uint32_t* pixel_xy = ctx->pixel_xy.as<uint32_t>();
         float4* sample_buf = ctx->sample_buf.as<float4>();
         launch_pixel_table(st, ctx->tiles.as<yk_tile>(), ctx->tile_off.as<uint32_t>(), (uint32_t)(t_end - t_begin), npx, pixel_xy);
+        // the second stream starts after the pixel table exists
+        if (n_ws == 2) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ws[0].done, st));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->ws[1].stream, ctx->ws[0].done, 0));
+        }
 
         const uint64_t work = (uint64_t)npx * spp;
+        int which = 0;
         for (uint64_t w0 = 0; w0 < work; w0 += batch) {
             if (cancel && cancel(user)) {
                 (void)hipStreamSynchronize(st);
+                if (n_ws == 2) (void)hipStreamSynchronize(ctx->ws[1].stream);
                 if (ev0) (void)hipEventDestroy(ev0);
                 if (ev1) (void)hipEventDestroy(ev1);
                 return fail(ctx, YK_ERR_CANCELLED, "cancelled by early_termination_predicate");
             }
+            WorkSet& ws = ctx->ws[which];
+            hipStream_t bs = n_ws == 2 ? ws.stream : st;
+            unsigned* ctrl = ws.ctrl.as<unsigned>();
             const uint32_t n = (uint32_t)std::min<uint64_t>(batch, work - w0);
-            HIP_TRY(ctx, hipMemsetAsync(ctrl, 0, YK_CTRL_WORDS * 4, st));
-            launch_raygen(st, cam, prm, pixel_xy, w0, n, path_buffers(ctx, 0), sample_buf, ctrl);
+            HIP_TRY(ctx, hipMemsetAsync(ctrl, 0, YK_CTRL_WORDS * 4, bs));
+            launch_raygen(bs, cam, prm, pixel_xy, w0, n, path_buffers(ws, 0), sample_buf, ctrl);
             ++n_batches;
             if (is_path) {
-                run_bounces(ctx, st, scene, prm, pixel_xy, nullptr, sample_buf, kt, counters);
+                run_bounces(ctx, ws, bs, scene, prm, pixel_xy, nullptr, sample_buf, kt, counters);
                 n_trace += prm.max_depth;
             } else {
-                PathBuffers pc = path_buffers(ctx, 0);
+                PathBuffers pc = path_buffers(ws, 0);
                 const bool want_stats = prm.integrator == YK_INTEGRATOR_BVH_INTERSECTIONS;
-                int e = kt.begin(st);
-                launch_trace_closest(st, trace_grid(ctx), scene->dev, pc.rayO, pc.rayD, nullptr, ctrl, ctrl + YK_CTRL_HEADS, ctx->hit.as<int>(), nullptr,
-                                     want_stats ? ctx->stats4.as<uint4>() : nullptr, ctx->spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), ctrl,
+                int e = kt.begin(bs);
+                launch_trace_closest(bs, trace_grid(ctx), scene->dev, pc.rayO, pc.rayD, nullptr, ctrl, ctrl + YK_CTRL_HEADS, ws.hit.as<int>(), nullptr,
+                                     want_stats ? ctx->stats4.as<uint4>() : nullptr, ws.spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), ctrl,
                                      counters);
-                kt.end(e, 0, st);
-                launch_debug_shade(st, scene->dev, prm.integrator, pc, ctx->hit.as<int>(), ctx->stats4.as<uint4>(), n, sample_buf);
+                kt.end(e, 0, bs);
+                launch_debug_shade(bs, scene->dev, prm.integrator, pc, ws.hit.as<int>(), ctx->stats4.as<uint4>(), n, sample_buf);
                 ++n_trace;
             }
+            if (n_ws == 2) which ^= 1;
+        }
+        if (n_ws == 2) {  // resolve (on the caller-visible stream) waits for the second stream
+            HIP_TRY(ctx, hipEventRecord(ctx->ws[1].done, ctx->ws[1].stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ws[1].done, 0));
         }
         launch_resolve(st, sample_buf, npx, spp, out + 3 * (size_t)px0);
         t_begin = t_end;
@@ -777,7 +824,12 @@ yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const y
         unsigned long long host_counters[8];
         unsigned host_ctrl[4];
         HIP_TRY(ctx, hipMemcpy(host_counters, counters, 64, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(host_ctrl, ctrl, 16, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(host_ctrl, ctx->ws[0].ctrl.p, 16, hipMemcpyDeviceToHost));
+        if (n_ws == 2) {
+            unsigned c1[4];
+            HIP_TRY(ctx, hipMemcpy(c1, ctx->ws[1].ctrl.p, 16, hipMemcpyDeviceToHost));
+            host_ctrl[YK_CTRL_ERR] |= c1[YK_CTRL_ERR];
+        }
         float ms = 0.0f;
         (void)hipEventElapsedTime(&ms, ev0, ev1);
         stats->rays = host_counters[0];
@@ -867,9 +919,9 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
     if (prm.max_depth > (YK_CTRL_WORDS - YK_CTRL_HEADS) / 2) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "max_depth too large");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    yk_status wb = ensure_work_buffers(ctx, n, scene->n_lights);
+    yk_status wb = ensure_work_buffers(ctx, ctx->ws[0], n, scene->n_lights);
     if (wb != YK_OK) return wb;
-    if ((wb = ensure_spill(ctx)) != YK_OK) return wb;
+    if ((wb = ensure_spill(ctx, ctx->ws[0])) != YK_OK) return wb;
     HIP_TRY(ctx, ctx->scratch[4].ensure(n * 12));
     HIP_TRY(ctx, ctx->scratch[5].ensure(n * 12));
     HIP_TRY(ctx, ctx->scratch[6].ensure(n * 4));
@@ -880,16 +932,16 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
     HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[5].p, ray_d, n * 12, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[6].p, pixel_xy, n * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[7].p, sample_index, n * 4, hipMemcpyHostToDevice, st));
-    unsigned* ctrl = ctx->ctrl.as<unsigned>();
+    unsigned* ctrl = ctx->ws[0].ctrl.as<unsigned>();
     unsigned long long* counters = ctx->counters.as<unsigned long long>();
     HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64, st));
     HIP_TRY(ctx, hipMemsetAsync(ctrl, 0, YK_CTRL_WORDS * 4, st));
     launch_raygen_user(st, prm, ctx->scratch[4].as<float>(), ctx->scratch[5].as<float>(), ctx->scratch[6].as<uint16_t>(), ctx->scratch[7].as<uint32_t>(),
-                       dimension, (uint32_t)n, path_buffers(ctx, 0), ctx->sample_buf.as<float4>(), ctx->pixel_xy.as<uint32_t>(), ctrl);
+                       dimension, (uint32_t)n, path_buffers(ctx->ws[0], 0), ctx->sample_buf.as<float4>(), ctx->pixel_xy.as<uint32_t>(), ctrl);
     KernelTimer kt;
     kt.ctx = ctx;
     kt.on = false;
-    run_bounces(ctx, st, scene, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), ctx->sample_buf.as<float4>(), kt, counters);
+    run_bounces(ctx, ctx->ws[0], st, scene, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), ctx->sample_buf.as<float4>(), kt, counters);
     HIP_TRY(ctx, hipGetLastError());
     std::vector<float> tmp(n * 4);
     HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->sample_buf.p, n * 16, hipMemcpyDeviceToHost, st));
@@ -913,9 +965,9 @@ yk_status yk_trace_closest(yk_context* ctx, const yk_scene* scene, size_t n, con
     if (n > 0xFFFFFF00ull) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many rays");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    yk_status wb = ensure_work_buffers(ctx, n, scene->n_lights);
+    yk_status wb = ensure_work_buffers(ctx, ctx->ws[0], n, scene->n_lights);
     if (wb != YK_OK) return wb;
-    if ((wb = ensure_spill(ctx)) != YK_OK) return wb;
+    if ((wb = ensure_spill(ctx, ctx->ws[0])) != YK_OK) return wb;
     const bool want_stats = out_node_tests || out_node_hits || out_shape_tests;
     HIP_TRY(ctx, ctx->scratch[4].ensure(n * 12));
     HIP_TRY(ctx, ctx->scratch[5].ensure(n * 12));
@@ -925,18 +977,18 @@ yk_status yk_trace_closest(yk_context* ctx, const yk_scene* scene, size_t n, con
     HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[4].p, ray_o, n * 12, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[5].p, ray_d, n * 12, hipMemcpyHostToDevice, st));
     if (t_max) HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[6].p, t_max, n * 4, hipMemcpyHostToDevice, st));
-    PathBuffers pb = path_buffers(ctx, 0);
+    PathBuffers pb = path_buffers(ctx->ws[0], 0);
     launch_pack_rays(st, n, ctx->scratch[4].as<float>(), ctx->scratch[5].as<float>(), pb.rayO, pb.rayD);
-    unsigned* ctrl = ctx->ctrl.as<unsigned>();
+    unsigned* ctrl = ctx->ws[0].ctrl.as<unsigned>();
     HIP_TRY(ctx, hipMemsetAsync(ctrl, 0, YK_CTRL_WORDS * 4, st));
     unsigned nn = (unsigned)n;
     HIP_TRY(ctx, hipMemcpyAsync(ctrl, &nn, 4, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     launch_trace_closest(st, trace_grid(ctx), scene->dev, pb.rayO, pb.rayD, t_max ? ctx->scratch[6].as<float>() : nullptr, ctrl, ctrl + YK_CTRL_HEADS,
-                         ctx->hit.as<int>(), ctx->hit4.as<float4>(), want_stats ? ctx->stats4.as<uint4>() : nullptr, ctx->spill.as<uint2>(),
+                         ctx->ws[0].hit.as<int>(), ctx->hit4.as<float4>(), want_stats ? ctx->stats4.as<uint4>() : nullptr, ctx->ws[0].spill.as<uint2>(),
                          trace_grid(ctx) * trace_block_size(), ctrl, nullptr);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(out_shape, ctx->hit.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(out_shape, ctx->ws[0].hit.p, n * 4, hipMemcpyDeviceToHost, st));
     std::vector<float> h4;
     if (out_t || out_bary) {
         h4.resize(n * 4);
@@ -973,9 +1025,9 @@ yk_status yk_trace_any(yk_context* ctx, const yk_scene* scene, size_t n, const f
     if (n > 0xFFFFFF00ull) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many rays");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    yk_status wb = ensure_work_buffers(ctx, n, scene->n_lights);
+    yk_status wb = ensure_work_buffers(ctx, ctx->ws[0], n, scene->n_lights);
     if (wb != YK_OK) return wb;
-    if ((wb = ensure_spill(ctx)) != YK_OK) return wb;
+    if ((wb = ensure_spill(ctx, ctx->ws[0])) != YK_OK) return wb;
     HIP_TRY(ctx, ctx->scratch[4].ensure(n * 12));
     HIP_TRY(ctx, ctx->scratch[5].ensure(n * 12));
     HIP_TRY(ctx, ctx->scratch[6].ensure(n * 4));
@@ -985,16 +1037,16 @@ yk_status yk_trace_any(yk_context* ctx, const yk_scene* scene, size_t n, const f
     HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[6].p, t_max, n * 4, hipMemcpyHostToDevice, st));
     if (area_light) HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[7].p, area_light, n * 4, hipMemcpyHostToDevice, st));
     launch_pack_shadow_rays(st, n, ctx->scratch[4].as<float>(), ctx->scratch[5].as<float>(), ctx->scratch[6].as<float>(),
-                            area_light ? ctx->scratch[7].as<int>() : nullptr, ctx->shO.as<float4>(), ctx->shD.as<float4>());
-    unsigned* ctrl = ctx->ctrl.as<unsigned>();
+                            area_light ? ctx->scratch[7].as<int>() : nullptr, ctx->ws[0].shO.as<float4>(), ctx->ws[0].shD.as<float4>());
+    unsigned* ctrl = ctx->ws[0].ctrl.as<unsigned>();
     HIP_TRY(ctx, hipMemsetAsync(ctrl, 0, YK_CTRL_WORDS * 4, st));
     unsigned nn = (unsigned)n;
     HIP_TRY(ctx, hipMemcpyAsync(ctrl, &nn, 4, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    launch_trace_any(st, trace_grid(ctx), scene->dev, ctx->shO.as<float4>(), ctx->shD.as<float4>(), nullptr, ctrl, ctrl + YK_CTRL_HEADS,
-                     ctx->vis.as<unsigned char>(), ctx->spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), ctrl, nullptr);
+    launch_trace_any(st, trace_grid(ctx), scene->dev, ctx->ws[0].shO.as<float4>(), ctx->ws[0].shD.as<float4>(), nullptr, ctrl, ctrl + YK_CTRL_HEADS,
+                     ctx->ws[0].vis.as<unsigned char>(), ctx->ws[0].spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), ctrl, nullptr);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(out_hit, ctx->vis.p, n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(out_hit, ctx->ws[0].vis.p, n, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return YK_OK;
 }
@@ -1033,7 +1085,7 @@ yk_status yk_camera_rays(yk_context* ctx, const yk_camera* camera, const yk_samp
     hipStream_t st = ctx->stream;
     const uint32_t npx = (uint32_t)(tile->x1 - tile->x0) * (uint32_t)(tile->y1 - tile->y0);
     const uint32_t spp = prm.sampler.spp;
-    yk_status wb = ensure_work_buffers(ctx, (size_t)npx * spp, 1);
+    yk_status wb = ensure_work_buffers(ctx, ctx->ws[0], (size_t)npx * spp, 1);
     if (wb != YK_OK) return wb;
     uint32_t off[2] = {0, npx};
     HIP_TRY(ctx, ctx->tiles.ensure(sizeof(yk_tile)));
@@ -1049,8 +1101,8 @@ yk_status yk_camera_rays(yk_context* ctx, const yk_camera* camera, const yk_samp
     DevCamera cam;
     std::memcpy(cam.c2w, camera->camera_to_world, 64);
     std::memcpy(cam.r2c, camera->raster_to_camera, 64);
-    PathBuffers pb = path_buffers(ctx, 0);
-    launch_raygen(st, cam, prm, ctx->pixel_xy.as<uint32_t>(), 0, npx * spp, pb, ctx->sample_buf.as<float4>(), ctx->ctrl.as<unsigned>());
+    PathBuffers pb = path_buffers(ctx->ws[0], 0);
+    launch_raygen(st, cam, prm, ctx->pixel_xy.as<uint32_t>(), 0, npx * spp, pb, ctx->sample_buf.as<float4>(), ctx->ws[0].ctrl.as<unsigned>());
     launch_unpack_rays(st, (size_t)npx * spp, pb.rayO, pb.rayD, ctx->scratch[4].as<float>(), ctx->scratch[5].as<float>());
     HIP_TRY(ctx, hipGetLastError());
     std::vector<float> o((size_t)npx * spp * 3), d((size_t)npx * spp * 3);
