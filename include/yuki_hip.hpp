@@ -1,0 +1,166 @@
+// yuki_hip.hpp — header-only C++17 mirror of the reference's interface for the Path
+// hot path, over the C ABI of yuki_hip.h.  Names follow yuki's Rust types:
+//
+//   FilmSettings / FilmTile / film_tiles()     yuki/src/film.rs:14-65,409-475
+//   CameraParameters / FoV / Camera            yuki/src/camera.rs:19-114
+//   SamplerType::Uniform / ::Stratified        yuki/src/sampling/mod.rs:16-31
+//   IntegratorType::Path(PathParams)           yuki/src/integrators/mod.rs:33-53
+//   Integrator::render(scene, camera, sampler, tile, tile_pixels) -> ray count
+//                                              yuki/src/integrators/mod.rs:120-185
+//   Scene                                      yuki/src/scene/mod.rs:41-49
+//
+// Where the reference panics (assert!/unwrap) this wrapper throws yuki::Error
+// carrying the yk_status.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "yuki_hip.h"
+
+namespace yuki {
+
+struct Error : std::runtime_error {
+    yk_status status;
+    Error(yk_status s, const std::string& what) : std::runtime_error(what), status(s) {}
+};
+
+inline void check(yk_status s, const yk_context* ctx = nullptr) {
+    if (s == YK_OK) return;
+    std::string msg = yk_status_string(s);
+    if (ctx) {
+        char buf[512] = {0};
+        if (yk_last_error(ctx, buf, sizeof(buf)) == YK_OK && buf[0]) msg += std::string(": ") + buf;
+    }
+    throw Error(s, msg);
+}
+
+// film.rs:14-39
+struct FilmSettings {
+    uint16_t res_x = 640, res_y = 480;
+    uint16_t tile_dim = 16;
+    bool clear = true, accumulate = false, sixteenth_res = false;
+};
+// film.rs:43-65
+using FilmTile = yk_tile;
+
+// film.rs:409-475 — clipped tiles in outward-spiral order
+inline std::vector<FilmTile> film_tiles(const FilmSettings& fs) {
+    std::vector<FilmTile> t(yk_film_tiles(fs.res_x, fs.res_y, fs.tile_dim, nullptr, 0));
+    yk_film_tiles(fs.res_x, fs.res_y, fs.tile_dim, t.data(), t.size());
+    return t;
+}
+
+enum class FoV { X = 0, Y = 1 };
+// camera.rs:24-41
+struct CameraParameters {
+    std::array<float, 3> position{0, 0, 0}, target{0, 0, 0}, up{0, 1, 0};
+    FoV fov_axis = FoV::X;
+    float fov_degrees = 0.0f;
+};
+// camera.rs:19-22,52-102
+struct Camera {
+    yk_camera matrices;
+    Camera(const CameraParameters& p, const FilmSettings& fs) {
+        yk_camera_params cp{};
+        for (int k = 0; k < 3; ++k) {
+            cp.position[k] = p.position[k];
+            cp.target[k] = p.target[k];
+            cp.up[k] = p.up[k];
+        }
+        cp.fov_axis = (uint32_t)p.fov_axis;
+        cp.fov_degrees = p.fov_degrees;
+        cp.res_x = fs.res_x;
+        cp.res_y = fs.res_y;
+        check(yk_camera_init(&cp, &matrices));
+    }
+};
+
+// sampling/mod.rs:16-31; the seed is explicit (default: the reference's commented debug seed, uniform.rs:35)
+struct SamplerType {
+    static constexpr uint64_t DEBUG_SEED = 0x73B9642E74AC471CULL;
+    static yk_sampler_desc Uniform(uint32_t pixel_samples, uint64_t seed = DEBUG_SEED) { return yk_sampler_desc{YK_SAMPLER_UNIFORM, pixel_samples, 1, 1, seed}; }
+    static yk_sampler_desc Stratified(uint32_t nx, uint32_t ny, bool jitter_samples = true, uint64_t seed = DEBUG_SEED) {
+        return yk_sampler_desc{YK_SAMPLER_STRATIFIED, nx, ny, jitter_samples ? 1u : 0u, seed};
+    }
+};
+
+// integrators/path.rs:20-32
+struct PathParams {
+    uint32_t max_depth = 3;
+    bool has_indirect_clamp = false;
+    float indirect_clamp = 0.0f;
+};
+struct IntegratorType {
+    static yk_integrator_desc Path(const PathParams& p = PathParams()) { return yk_integrator_desc{YK_INTEGRATOR_PATH, p.max_depth, p.has_indirect_clamp ? 1u : 0u, p.indirect_clamp}; }
+    static yk_integrator_desc BVHIntersections() { return yk_integrator_desc{YK_INTEGRATOR_BVH_INTERSECTIONS, 1, 0, 0.0f}; }
+    static yk_integrator_desc GeometryNormals() { return yk_integrator_desc{YK_INTEGRATOR_GEOMETRY_NORMALS, 1, 0, 0.0f}; }
+    static yk_integrator_desc ShadingNormals() { return yk_integrator_desc{YK_INTEGRATOR_SHADING_NORMALS, 1, 0, 0.0f}; }
+};
+
+class Context {
+   public:
+    explicit Context(int device = 0) { check(yk_context_create(device, &h_)); }
+    ~Context() { yk_context_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    yk_context* handle() const { return h_; }
+    void set_option(const char* key, int64_t v) { check(yk_context_set_option(h_, key, v), h_); }
+
+   private:
+    yk_context* h_ = nullptr;
+};
+
+// scene/mod.rs:41-49.  ctx == nullptr: host-only (BVH build / export, no GPU).
+class Scene {
+   public:
+    Scene(Context* ctx, const yk_scene_desc& desc) : ctx_(ctx) { check(yk_scene_create(ctx ? ctx->handle() : nullptr, &desc, &h_), ctx ? ctx->handle() : nullptr); }
+    ~Scene() { yk_scene_destroy(h_); }
+    Scene(const Scene&) = delete;
+    Scene& operator=(const Scene&) = delete;
+    yk_scene* handle() const { return h_; }
+    yk_scene_info info() const {
+        yk_scene_info i;
+        check(yk_scene_get_info(h_, &i));
+        return i;
+    }
+    std::pair<std::vector<yk_bvh_node>, std::vector<uint32_t>> export_bvh() const {
+        yk_scene_info i = info();
+        std::vector<yk_bvh_node> nodes(i.n_nodes);
+        std::vector<uint32_t> order(i.n_shapes);
+        check(yk_scene_export_bvh(h_, nodes.data(), order.data()));
+        return {std::move(nodes), std::move(order)};
+    }
+
+   private:
+    Context* ctx_;
+    yk_scene* h_ = nullptr;
+};
+
+// trait Integrator, integrators/mod.rs:92-186
+class Integrator {
+   public:
+    Integrator(Context& ctx, yk_integrator_desc desc) : ctx_(ctx), desc_(desc) {}
+    // render(): one tile; tile_pixels holds >= tile area RGB triples; returns the ray count
+    size_t render(const Scene& scene, const Camera& camera, const yk_sampler_desc& sampler, const FilmTile& tile, float* tile_pixels) const {
+        uint64_t rays = 0;
+        check(yk_render_tile(ctx_.handle(), scene.handle(), &camera.matrices, &sampler, &desc_, &tile, tile_pixels, &rays), ctx_.handle());
+        return (size_t)rays;
+    }
+    // all tiles of a GPU worker in one submission; out_rgb tile-major
+    yk_render_stats render_tiles(const Scene& scene, const Camera& camera, const yk_sampler_desc& sampler, const std::vector<FilmTile>& tiles, float* out_rgb,
+                                 yk_cancel_fn cancel = nullptr, void* user = nullptr) const {
+        yk_render_stats st{};
+        check(yk_render_tiles(ctx_.handle(), scene.handle(), &camera.matrices, &sampler, &desc_, tiles.data(), tiles.size(), out_rgb, &st, cancel, user), ctx_.handle());
+        return st;
+    }
+
+   private:
+    Context& ctx_;
+    yk_integrator_desc desc_;
+};
+
+}  // namespace yuki

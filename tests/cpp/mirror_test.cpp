@@ -1,0 +1,97 @@
+// Exercises include/yuki_hip.hpp: host-side pieces always; with a GPU (argv[1] == "gpu")
+// Integrator::render on one tile and render_tiles on the whole film.  Prints
+// key=value lines that tests/test_cxx_mirror.py checks.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "yuki_hip.hpp"
+
+int main(int argc, char** argv) {
+    using namespace yuki;
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+    // two stacked quads (4 triangles) lit by a point light
+    std::vector<float> pts = {-1, 0, -1, 1, 0, -1, 1, 0, 1, -1, 0, 1, -0.5f, 0.5f, -0.5f, 0.5f, 0.5f, -0.5f, 0.5f, 0.5f, 0.5f, -0.5f, 0.5f, 0.5f};
+    std::vector<uint32_t> idx = {0, 2, 1, 0, 3, 2, 4, 6, 5, 4, 7, 6};
+    std::vector<uint32_t> tri_mesh = {0, 0, 0, 0};
+    std::vector<int32_t> tri_mat = {0, 0, 1, 1}, tri_al = {-1, -1, -1, -1};
+    yk_mesh_desc mesh = {0, 0, 0, 0};
+    yk_material_desc mats[2] = {};
+    mats[0].kind = YK_MAT_MATTE;
+    mats[0].a[0] = mats[0].a[1] = mats[0].a[2] = 0.8f;
+    mats[1].kind = YK_MAT_GLASS;
+    for (int k = 0; k < 3; ++k) mats[1].a[k] = mats[1].b[k] = 1.0f;
+    mats[1].c = 1.5f;
+    const float l2w[16] = {1, 0, 0, 0, 0, 1, 0, 3, 0, 0, 1, 0, 0, 0, 0, 1};
+    const float intensity[3] = {30, 30, 30};
+    yk_light_desc light;
+    check(yk_make_point_light(l2w, intensity, &light));
+    yk_scene_desc d{};
+    d.n_vertices = 8;
+    d.points = pts.data();
+    d.n_triangles = 4;
+    d.indices = idx.data();
+    d.tri_mesh = tri_mesh.data();
+    d.tri_material = tri_mat.data();
+    d.tri_area_light = tri_al.data();
+    d.n_meshes = 1;
+    d.meshes = &mesh;
+    d.n_materials = 2;
+    d.materials = mats;
+    d.n_lights = 1;
+    d.lights = &light;
+    d.background[0] = d.background[1] = d.background[2] = 0.1f;
+    d.split_method = YK_SPLIT_SAH;
+    d.max_shapes_in_node = 1;
+
+    FilmSettings fs;
+    fs.res_x = 40;
+    fs.res_y = 24;
+    std::vector<FilmTile> tiles = film_tiles(fs);
+    std::printf("tiles=%zu first=%u,%u last=%u,%u\n", tiles.size(), tiles.front().x0, tiles.front().y0, tiles.back().x1, tiles.back().y1);
+    CameraParameters cp;
+    cp.position = {0, 2, -3};
+    cp.target = {0, 0.3f, 0};
+    cp.fov_degrees = 50;
+    Camera cam(cp, fs);
+    std::printf("camera_c2w_03=%.6f\n", cam.matrices.camera_to_world[3]);
+    {
+        Scene host(nullptr, d);
+        auto bvh = host.export_bvh();
+        std::printf("nodes=%zu shapes=%zu depth=%u\n", bvh.first.size(), bvh.second.size(), host.info().tree_depth);
+    }
+    try {
+        d.max_shapes_in_node = 0;
+        Scene bad(nullptr, d);
+        std::printf("bad_scene=accepted\n");
+    } catch (const Error& e) {
+        std::printf("bad_scene=status%d\n", (int)e.status);
+    }
+    d.max_shapes_in_node = 1;
+    if (!gpu) return 0;
+
+    Context ctx(0);
+    Scene scene(&ctx, d);
+    Integrator path(ctx, IntegratorType::Path(PathParams{6, false, 0.0f}));
+    yk_sampler_desc smp = SamplerType::Stratified(2, 2);
+    std::vector<float> film((size_t)fs.res_x * fs.res_y * 3);
+    yk_render_stats st = path.render_tiles(scene, cam, smp, tiles, film.data());
+    double sum = 0;
+    for (float v : film) sum += v;
+    std::printf("rays=%llu samples=%llu mean=%.6f\n", (unsigned long long)st.rays, (unsigned long long)st.samples, sum / film.size());
+    // the trait method on the first tile equals the first tile of the batch
+    std::vector<float> tile_px(16 * 16 * 3);
+    size_t rays = path.render(scene, cam, smp, tiles[0], tile_px.data());
+    int w = tiles[0].x1 - tiles[0].x0, h = tiles[0].y1 - tiles[0].y0;
+    bool same = std::memcmp(tile_px.data(), film.data(), (size_t)w * h * 12) == 0;
+    std::printf("tile_rays=%zu tile_matches_batch=%d\n", rays, same ? 1 : 0);
+    try {
+        FilmTile bad{8, 8, 8, 12};
+        path.render(scene, cam, smp, bad, tile_px.data());
+        std::printf("bad_tile=accepted\n");
+    } catch (const Error& e) {
+        std::printf("bad_tile=status%d\n", (int)e.status);
+    }
+    return 0;
+}
