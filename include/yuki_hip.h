@@ -100,7 +100,7 @@ typedef struct yk_scene_desc {
     const int32_t* tri_area_light; /* n_triangles -> lights[] or -1 (Triangle.area_light, triangle.rs:22) */
     uint32_t n_meshes;
     const yk_mesh_desc* meshes;
-    uint32_t n_spheres; /* shapes are ordered: triangles, then spheres */
+    uint32_t n_spheres; /* shape ids: triangles first, then spheres (see shape_order) */
     const yk_sphere_desc* spheres;
     uint32_t n_materials;
     const yk_material_desc* materials;
@@ -109,6 +109,10 @@ typedef struct yk_scene_desc {
     float background[3];
     uint32_t split_method;       /* yk_split_method */
     uint32_t max_shapes_in_node; /* scene/mod.rs:36 default 1 */
+    /* Order in which the shapes enter BoundingVolumeHierarchy::new (Scene.shapes, which the
+     * pbrt loader fills in file order): n_triangles + n_spheres entries, entry < n_triangles
+     * = that triangle, otherwise sphere (entry - n_triangles).  NULL = triangles, then spheres. */
+    const uint32_t* shape_order;
 } yk_scene_desc;
 
 /* camera.rs:19-22 `Camera` = two Transforms */
@@ -277,6 +281,29 @@ yk_status yk_bsdf_sample(yk_context* ctx, const yk_material_desc* material, size
                          const float* n_shading, const float* dpdu, const float* wo, const float* u, float* out8);
 
 size_t yk_sizeof(int what);
+
+/* ---- scene input -------------------------------------------
+ * The reference's loaders, host-only (no device needed): they produce the flattened
+ * scene description yk_scene_create consumes plus the camera and film settings the
+ * reference's `load` functions return.
+ *   yk_load_ply   Scene::ply          scene/mod.rs:99-152 + ply::load scene/ply.rs:19-130
+ *                 (white matte, fit-to-unit-cube transform, point light, 640x480 camera)
+ *   yk_load_pbrt  scene::pbrt::load   scene/pbrt/mod.rs:94-857 — the subset the reference
+ *                 implements: perspective Camera, Film resolution, LookAt, Translate/Scale/
+ *                 Rotate, Attribute/Transform blocks, Include, (Make)NamedMaterial/Material
+ *                 {matte,glass,glossy,metal}, LightSource {infinite,distant,point}, Shape
+ *                 {sphere,trianglemesh,plymesh}; image textures are not supported yet.
+ * split_method / max_shapes_in_node are SceneLoadSettings (scene/mod.rs:25-39) and are
+ * copied into the description.  Errors: where the reference returns LoadError or panics
+ * the call returns non-zero and yk_loader_last_error() (thread-local) holds the reason. */
+typedef struct yk_loaded_scene yk_loaded_scene;
+yk_status yk_load_ply(const char* path, uint32_t split_method, uint32_t max_shapes_in_node, yk_loaded_scene** out);
+yk_status yk_load_pbrt(const char* path, uint32_t split_method, uint32_t max_shapes_in_node, yk_loaded_scene** out);
+/* Pointers written into *desc stay valid until yk_loaded_scene_destroy.  camera->res_x/res_y
+ * carry FilmSettings.res; *tile_dim its tile_dim (16).  camera / tile_dim may be NULL. */
+yk_status yk_loaded_scene_get(const yk_loaded_scene* loaded, yk_scene_desc* desc, yk_camera_params* camera, uint16_t* tile_dim);
+void yk_loaded_scene_destroy(yk_loaded_scene* loaded);
+const char* yk_loader_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,758 @@
+"""TEST INFRASTRUCTURE ONLY — CPU restatement of the reference's scene loaders.
+
+Only tests/ may import this module; the product (yuki_amd/) never does.  It restates,
+independently of yuki_amd/csrc/yk_loaders.cpp, what the reference does when it reads
+
+    a PLY file      yuki/src/scene/ply.rs:19-130,217-284 and Scene::ply, scene/mod.rs:99-152
+                    (payload decoding is the published PLY format as implemented by the
+                    ply-rs 0.1 crate — a Cargo dependency that is not under /root/reference)
+    a pbrt-v3 file  yuki/src/scene/pbrt/{mod,lexer,param_set,cie}.rs
+
+in plain Python/numpy float32 arithmetic.  Transform products, rotations, point/normal
+transforms and vector normalisation go through the liboracle.so restatement of the
+reference's math (oracle_api.h `orc_*_f32`), which is pinned by the reference's own
+unit-test vectors (tests/golden/reference_math_kats.json).
+
+Parity unpinned: the reference holds no tests, fixtures or sample files for its
+loaders; these functions follow its source text only.
+"""
+import ctypes as C
+import math
+import os
+import struct
+
+import numpy as np
+
+from yuki_amd import abi
+from yuki_amd.scenes import SceneData
+
+from . import binding
+
+F = np.float32
+_libc = C.CDLL(None)
+_libc.strtof.restype = C.c_float
+_libc.strtof.argtypes = [C.c_char_p, C.c_void_p]
+
+
+def parse_f32(tok):
+    """str::parse::<f32>: correctly rounded decimal -> binary32 (no detour through f64)."""
+    float(tok)  # syntax check (raises ValueError like the reference's unwrap/Err)
+    return F(_libc.strtof(tok.encode(), None))
+
+
+class LoadError(Exception):
+    pass
+
+
+# ------------------------------------------------------------------ transforms (through liboracle)
+def _f16(m):
+    return np.ascontiguousarray(m, dtype=F).reshape(16)
+
+
+class Xf:
+    """Transform<f32>: matrix + inverse (math/transform.rs:12-19)."""
+
+    def __init__(self, m=None, mi=None):
+        self.m = np.eye(4, dtype=F) if m is None else np.asarray(m, dtype=F).reshape(4, 4)
+        self.mi = np.eye(4, dtype=F) if mi is None else np.asarray(mi, dtype=F).reshape(4, 4)
+
+    def __mul__(self, o):  # transform.rs:211-223: (a.m * b.m, b.m_inv * a.m_inv)
+        L = binding.lib()
+        m = np.zeros(16, dtype=F)
+        mi = np.zeros(16, dtype=F)
+        L.orc_mat4_mul_f32(binding._p(_f16(self.m)), binding._p(_f16(o.m)), binding._p(m))
+        L.orc_mat4_mul_f32(binding._p(_f16(o.mi)), binding._p(_f16(self.mi)), binding._p(mi))
+        return Xf(m, mi)
+
+    def apply(self, what, v):
+        out = np.zeros(3, dtype=F)
+        binding.lib().orc_transform_apply_f32(binding._p(_f16(self.m)), binding._p(_f16(self.mi)), what, binding._p(np.ascontiguousarray(v, dtype=F)), binding._p(out))
+        return out
+
+    def swaps_handedness(self):  # transform.rs:85-91
+        m = self.m
+        det = m[0, 0] * (m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) - m[0, 1] * (m[1, 0] * m[2, 2] - m[1, 2] * m[2, 0]) + m[0, 2] * (m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0])
+        return bool(det < 0)
+
+
+def translation(d):  # transforms.rs:4-23
+    m = np.eye(4, dtype=F)
+    mi = np.eye(4, dtype=F)
+    for k in range(3):
+        m[k, 3] = F(d[k])
+        mi[k, 3] = -F(d[k])
+    return Xf(m, mi)
+
+
+def scale(x, y, z):  # transforms.rs:26-45
+    m = np.eye(4, dtype=F)
+    mi = np.eye(4, dtype=F)
+    for k, v in enumerate((x, y, z)):
+        m[k, k] = F(v)
+        mi[k, k] = F(1.0) / F(v)
+    return Xf(m, mi)
+
+
+def rotation(theta, axis):  # transforms.rs:98-127
+    m = np.zeros(16, dtype=F)
+    mi = np.zeros(16, dtype=F)
+    binding.lib().orc_rotation_f32(3, C.c_float(float(theta)), binding._p(np.ascontiguousarray(axis, dtype=F)), binding._p(m), binding._p(mi))
+    return Xf(m, mi)
+
+
+def normalized(v):
+    out = np.zeros(9, dtype=F)
+    a = np.ascontiguousarray(v, dtype=F)
+    binding.lib().orc_vec3_ops_f32(binding._p(a), binding._p(a), binding._p(out))
+    return out[5:8].copy()
+
+
+RADS_PER_DEG = F(F(math.pi) / F(180.0))  # f32::to_radians
+
+
+# ------------------------------------------------------------------ scene accumulation
+class _Accum:
+    def __init__(self):
+        self.points, self.normals, self.uvs = [], [], []
+        self.indices, self.tri_mesh, self.tri_material = [], [], []
+        self.meshes, self.spheres, self.materials, self.lights = [], [], [], []
+        self.order = []  # ('t', tri id) | ('s', sphere id) in Scene.shapes order
+        self.background = (F(0), F(0), F(0))
+        self.nv = 0
+        self.any_n = self.any_uv = False
+
+    def add_mesh(self, xf, idx, pts, nrm, uv, material):
+        """Mesh::new (shapes/mesh.rs:20-43) + one Triangle per index triple."""
+        base = self.nv
+        nv = len(pts)
+        self.points.extend(xf.apply(1, p) for p in pts)
+        self.normals.extend([xf.apply(2, n) for n in nrm] if nrm else [np.zeros(3, F)] * nv)
+        self.uvs.extend([np.asarray(t, F) for t in uv] if uv else [np.zeros(2, F)] * nv)
+        self.any_n |= bool(nrm)
+        self.any_uv |= bool(uv)
+        self.nv += nv
+        mesh_id = len(self.meshes)
+        self.meshes.append((bool(nrm), bool(uv), xf.swaps_handedness()))
+        for k in range(0, len(idx) - 2, 3):
+            self.order.append(("t", len(self.indices)))
+            self.indices.append([base + idx[k], base + idx[k + 1], base + idx[k + 2]])
+            self.tri_mesh.append(mesh_id)
+            self.tri_material.append(material)
+
+    def finish(self, split_method, max_shapes_in_node, camera, film_res, name):
+        nt = len(self.indices)
+        order = np.array([i if k == "t" else nt + i for k, i in self.order], dtype=np.uint32)
+        lights = []
+        for l in self.lights:
+            s = abi.LightDesc()
+            if l[0] == "point":
+                binding.LightFactory.make_point_light(l[1].m, l[2], s)
+            else:
+                s.kind = abi.LIGHT_DISTANT
+                s.p = abi.f3(l[1])
+                s.i = abi.f3(l[2])
+            lights.append(s)
+        sd = SceneData(
+            points=np.array(self.points, dtype=F).reshape(-1, 3),
+            indices=np.array(self.indices, dtype=np.uint32).reshape(-1, 3),
+            tri_mesh=np.array(self.tri_mesh, dtype=np.uint32),
+            tri_material=np.array(self.tri_material, dtype=np.int32),
+            tri_area_light=np.full(nt, -1, dtype=np.int32),
+            meshes=self.meshes,
+            materials=self.materials,
+            lights=[],
+            normals=np.array(self.normals, dtype=F).reshape(-1, 3) if self.any_n else None,
+            uvs=np.array(self.uvs, dtype=F).reshape(-1, 2) if self.any_uv else None,
+            spheres=self.spheres,
+            background=tuple(self.background),
+            split_method=split_method,
+            max_shapes_in_node=max_shapes_in_node,
+            camera=camera,
+            name=name,
+            shape_order=order,
+            film_res=film_res,
+        )
+        sd.light_structs = lights
+        return sd
+
+
+# ------------------------------------------------------------------ PLY
+_PLY_TYPES = {
+    "char": ("b", 1), "int8": ("b", 1), "uchar": ("B", 1), "uint8": ("B", 1), "short": ("h", 2), "int16": ("h", 2), "ushort": ("H", 2), "uint16": ("H", 2),
+    "int": ("i", 4), "int32": ("i", 4), "uint": ("I", 4), "uint32": ("I", 4), "float": ("f", 4), "float32": ("f", 4), "double": ("d", 8), "float64": ("d", 8),
+}
+_F32 = ("float", "float32")
+_I32U32 = ("int", "int32", "uint", "uint32")
+
+
+def _read_ply(path):
+    """-> (points [(x,y,z) f32], normals, uvs, faces [[int]]) with the reference's property rules."""
+    with open(path, "rb") as f:
+        data = f.read()
+    pos = 0
+
+    def line():
+        nonlocal pos
+        e = data.index(b"\n", pos) if b"\n" in data[pos:] else len(data)
+        l = data[pos:e].decode("ascii", "replace").rstrip("\r")
+        pos = min(e + 1, len(data))
+        return l
+
+    if line() != "ply":
+        raise LoadError("PLY: missing magic")
+    fmt, elements = None, []
+    while True:
+        if pos >= len(data):
+            raise LoadError("PLY: bad header")
+        w = line().split()
+        if not w:
+            continue
+        if w[0] == "format":
+            fmt = w[1]
+        elif w[0] == "element":
+            elements.append(dict(name=w[1], count=int(w[2]), props=[]))
+        elif w[0] == "property":
+            if w[1] == "list":
+                elements[-1]["props"].append(dict(name=w[4], list=True, ctype=w[2], type=w[3]))
+            else:
+                elements[-1]["props"].append(dict(name=w[2], list=False, type=w[1]))
+        elif w[0] == "end_header":
+            break
+    by_name = {e["name"]: e for e in elements}
+    # is_valid, ply.rs:146-215
+    ok = "vertex" in by_name and "face" in by_name
+    if ok:
+        vn = {p["name"] for p in by_name["vertex"]["props"]}
+        fn = {p["name"] for p in by_name["face"]["props"]}
+        ok = {"x", "y", "z"} <= vn and bool({"vertex_index", "vertex_indices"} & fn)
+    if not ok:
+        raise LoadError("PLY: Unsupported content")
+    ascii_mode = fmt == "ascii"
+    end = "<" if fmt == "binary_little_endian" else ">"
+    toks = data[pos:].split() if ascii_mode else None
+    ti = 0
+
+    def scalar(tname):
+        nonlocal ti, pos
+        code, size = _PLY_TYPES[tname]
+        if ascii_mode:
+            if ti >= len(toks):
+                raise LoadError("PLY: truncated payload")
+            t = toks[ti].decode()
+            ti += 1
+            if tname in _F32:
+                return parse_f32(t)
+            return float(t) if code == "d" else int(t)
+        if pos + size > len(data):
+            raise LoadError("PLY: truncated payload")
+        (v,) = struct.unpack_from(end + code, data, pos)
+        pos += size
+        return F(v) if code == "f" else v
+
+    pts, nrm, uvs, faces = [], [], [], []
+    for e in elements:
+        for _ in range(e["count"]):
+            P = [F(0), F(0), F(0)]
+            N = UV = None
+            face = None
+            for p in e["props"]:
+                if not p["list"]:
+                    v = scalar(p["type"])
+                    if e["name"] == "vertex" and p["type"] in _F32:  # Property::Float only
+                        n = p["name"]
+                        if n in "xyz" and len(n) == 1:
+                            P["xyz".index(n)] = v
+                        elif n == "nx":
+                            N = [v, F(0), F(0)]
+                        elif n in ("ny", "nz"):
+                            if N is None:
+                                raise LoadError("PLY: normal component before nx")
+                            N[1 if n == "ny" else 2] = v
+                        elif n == "u":
+                            UV = [v, F(0)]
+                        elif n == "v":
+                            if UV is None:
+                                raise LoadError("PLY: v before u")
+                            UV[1] = v
+                else:
+                    cnt = int(scalar(p["ctype"]))
+                    items = [int(scalar(p["type"])) for _ in range(cnt)]
+                    if e["name"] == "face" and p["name"] in ("vertex_index", "vertex_indices") and p["type"] in _I32U32:
+                        face = items
+            if e["name"] == "vertex":
+                pts.append(P)
+                if N is not None:
+                    nrm.append(N)
+                if UV is not None:
+                    uvs.append(UV)
+            elif e["name"] == "face":
+                if not face:
+                    raise LoadError("PLY: face without indices")  # reference: f.indices[0] panics
+                if min(face) < 0:
+                    raise LoadError("Negative PLY index")
+                faces.append(face)
+    return pts, nrm, uvs, faces
+
+
+def _ply_mesh(acc, path, xf, material):
+    """ply::load, ply.rs:19-130."""
+    pts, nrm, uvs, faces = _read_ply(path)
+    idx = []
+    for f in faces:  # fan: (v0, v_k, v_k+1)
+        for k in range(1, len(f) - 1):
+            idx += [f[0], f[k], f[k + 1]]
+    if not pts or not idx:
+        raise LoadError("PLY: empty mesh")
+    if max(idx) >= len(pts) or (nrm and len(nrm) != len(pts)) or (uvs and len(uvs) != len(pts)):
+        raise LoadError("PLY: inconsistent attribute counts")
+    if xf is None:
+        a = np.array(pts, dtype=F)
+        lo, hi = a.min(axis=0), a.max(axis=0)  # Bounds3::default().union_p over finite points
+        diag = hi - lo
+        center = lo + diag / F(2.0)
+        mesh_scale = F(1.0) / max(diag[0], max(diag[1], diag[2]))
+        xf = scale(mesh_scale, mesh_scale, mesh_scale) * translation(-center)
+    acc.add_mesh(xf, idx, pts, nrm, uvs, material)
+
+
+def load_ply(path, split_method=abi.SPLIT_SAH, max_shapes_in_node=1):
+    """Scene::ply, scene/mod.rs:99-152 -> (SceneData, camera dict, film_res)."""
+    acc = _Accum()
+    acc.materials.append(dict(kind=abi.MAT_MATTE, a=(1.0, 1.0, 1.0), b=(0, 0, 0), c=0.0, remap=False))
+    _ply_mesh(acc, path, None, 0)
+    acc.lights.append(("point", translation((5.0, 5.0, 0.0)), (F(1.0) * F(600.0),) * 3))
+    camera = dict(position=(2.0, 2.0, 2.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov_axis=abi.FOV_X, fov_degrees=40.0)
+    sd = acc.finish(split_method, max_shapes_in_node, camera, (640, 480), os.path.basename(path))
+    sd.shape_order = None  # a single mesh: natural order
+    return sd, camera, (640, 480)
+
+
+# ------------------------------------------------------------------ pbrt-v3
+_DIRECTIVES = {
+    "Accelerator", "ActiveTransform", "All", "AreaLightSource", "AttributeBegin", "AttributeEnd", "Camera", "ConcatTransform", "CoordinateSystem",
+    "CoordSysTransform", "EndTime", "Film", "Identity", "Include", "Integrator", "LightSource", "LookAt", "MakeNamedMedium", "MakeNamedMaterial",
+    "Material", "MediumInterface", "NamedMaterial", "ObjectBegin", "ObjectEnd", "ObjectInstance", "PixelFilter", "ReverseOrientation", "Rotate",
+    "Sampler", "Scale", "Shape", "StartTime", "Texture", "TransformBegin", "TransformEnd", "TransformTimes", "Transform", "Translate", "WorldBegin", "WorldEnd",
+}
+_WS = " \t\r\n"
+
+
+class _Eof(Exception):
+    pass
+
+
+class _Lexer:
+    """pbrt/lexer.rs:68-245, character by character."""
+
+    def __init__(self, text):
+        self.s, self.i = text, 0
+
+    def get(self):
+        if self.i < len(self.s):
+            c = self.s[self.i]
+            self.i += 1
+            return c
+        return None
+
+    def next(self):
+        while True:
+            c = self.get()
+            if c is None:
+                raise _Eof()
+            if c not in _WS:
+                self.i -= 1
+                break
+        start = None
+        while True:
+            c = self.get()
+            if c is None:
+                raise _Eof()
+            if c == "#":
+                while True:
+                    c = self.get()
+                    if c is None:
+                        raise _Eof()
+                    if c in "\r\n":
+                        break
+                return self.next()
+            if c == '"':
+                st = self.i
+                while True:
+                    c = self.get()
+                    if c is None:
+                        raise LoadError("UnexpectedEndOfInput")
+                    if c == '"':
+                        return ("str", self.s[st : self.i - 1])
+                    if c == "\\":
+                        if self.get() is None:
+                            raise LoadError("UnexpectedEndOfInput")
+                    elif c == "\n":
+                        raise LoadError("UnterminatedString")
+            if c == "[":
+                return ("[", None)
+            if c in _WS or c == "]":
+                if start is not None:
+                    end = self.i - 1
+                    if c == "]":
+                        self.i -= 1
+                    return self.classify(self.s[start:end])
+                if c == "]":
+                    return ("]", None)
+            elif start is None:
+                start = self.i - 1
+
+    @staticmethod
+    def classify(t):
+        if t in _DIRECTIVES:
+            return ("id", t)
+        if t[0] in "-.0123456789":
+            low = t.lower().lstrip("+-")
+            if "_" in t or low.startswith("0x") or t != t.strip():
+                raise LoadError("InvalidNumber")
+            try:
+                return ("num", float(t))
+            except ValueError:
+                raise LoadError("InvalidNumber")
+        raise LoadError(f"UnknownIdentifier '{t}'")
+
+
+def _expf(x):
+    return F(math.exp(float(x)))
+
+
+def _fit(l, terms):
+    """pbrt/cie.rs: sum of c * exp(-0.5 * t^2), t = (l - mu) * (s1 if l < mu else s2), all f32."""
+    acc = None
+    for c, mu, s1, s2 in terms:
+        t = (l - F(mu)) * (F(s1) if l < F(mu) else F(s2))
+        v = F(abs(c)) * _expf(F(-0.5) * t * t)
+        acc = v if acc is None else (acc + v if c > 0 else acc - v)
+    return acc
+
+
+def _x_fit(l):
+    return _fit(l, [(0.362, 442.0, 0.0624, 0.0374), (1.056, 599.8, 0.0264, 0.0323), (-0.065, 501.1, 0.0490, 0.0382)])
+
+
+def _y_fit(l):
+    return _fit(l, [(0.821, 568.8, 0.0213, 0.0247), (0.286, 530.9, 0.0613, 0.0322)])
+
+
+def _z_fit(l):
+    return _fit(l, [(1.217, 437.0, 0.0845, 0.0278), (0.681, 459.0, 0.0385, 0.0725)])
+
+
+def sampled_spectrum_into_rgb(lam, smp):
+    """pbrt/mod.rs:979-1016 (the sort branch's result is discarded there, so input order is used)."""
+    X = Y = Z = F(0)
+    for l, s in zip(lam, smp):
+        l, s = F(l), F(s)
+        X = X + _x_fit(l) * s
+        Y = Y + _y_fit(l) * s
+        Z = Z + _z_fit(l) * s
+    k = (F(lam[-1]) - F(lam[0])) / F(len(lam))
+    X, Y, Z = X * k, Y * k, Z * k
+    return (
+        F(3.240479) * X - F(1.537150) * Y - F(0.498535) * Z,
+        F(-0.969256) * X + F(1.875991) * Y + F(0.041556) * Z,
+        F(0.055648) * X - F(0.204043) * Y + F(1.057311) * Z,
+    )
+
+
+def _copper():
+    """pbrt-v3's measured Cu n/k table (the defaults of `metal`), kept as test data."""
+    import json
+
+    with open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "copper_spd.json")) as f:
+        d = json.load(f)
+    return d["wavelengths"], d["n"], d["k"]
+
+
+class _Params:
+    """pbrt/param_set.rs: typed lists of (name, values), linear search."""
+
+    def __init__(self):
+        self.items = {k: [] for k in ("bool", "float", "int", "point", "normal", "uv", "spectrum", "string")}
+
+    def add(self, kind, name, values):
+        self.items[kind].append((name, values))
+
+    def one(self, kind, name, default):
+        for n, v in self.items[kind]:
+            if n == name and len(v) == 1:
+                return v[0]
+        return default
+
+    def many(self, kind, name):
+        for n, v in self.items[kind]:
+            if n == name:
+                return v
+        return []
+
+
+def _sat_i32(v):
+    if v != v:
+        return 0
+    return int(max(-2147483648.0, min(2147483647.0, v)))
+
+
+def _material(kind, ps, textures):
+    """get_material, pbrt/mod.rs:860-936 -> material dict."""
+    ones, half = (F(1),) * 3, (F(0.5),) * 3
+    if kind == "glass":
+        return dict(kind=abi.MAT_GLASS, a=ps.one("spectrum", "Kr", ones), b=ps.one("spectrum", "Kt", ones), c=ps.one("float", "eta", F(1.5)), remap=False)
+    if kind == "glossy":
+        return dict(kind=abi.MAT_GLOSSY, a=ps.one("spectrum", "Rs", half), b=(0, 0, 0), c=ps.one("float", "roughness", F(0.5)), remap=False)
+    if kind == "matte":
+        tex = ps.one("string", "Kd", "")
+        if tex:
+            raise LoadError(f"Texture '{tex}' " + ("unsupported" if tex in textures else "not found"))
+        sigma = ps.one("float", "sigma", F(0)) * RADS_PER_DEG
+        return dict(kind=abi.MAT_MATTE, a=ps.one("spectrum", "Kd", half), b=(0, 0, 0), c=sigma * RADS_PER_DEG, remap=False)
+    if kind == "metal":
+        lam, n, k = _copper()
+        return dict(
+            kind=abi.MAT_METAL, a=ps.one("spectrum", "eta", sampled_spectrum_into_rgb(lam, n)), b=ps.one("spectrum", "k", sampled_spectrum_into_rgb(lam, k)),
+            c=ps.one("float", "roughness", F(0.01)), remap=ps.one("bool", "remaproughness", True),
+        )
+    return dict(kind=abi.MAT_MATTE, a=(F(1) * F(0.5),) * 3, b=(0, 0, 0), c=F(0), remap=False)
+
+
+def load_pbrt(path, split_method=abi.SPLIT_SAH, max_shapes_in_node=1):
+    """scene::pbrt::load, pbrt/mod.rs:94-857 -> (SceneData, camera dict, film_res)."""
+    acc = _Accum()
+    acc.materials.append(_material("matte", _Params(), {}))  # default_material
+    st = dict(
+        xf=Xf(), xf_stack=[], gs_stack=[], atb_stack=[], named={}, textures=set(), material=0, start=True, fetched=None,
+        cam=dict(position=(F(0),) * 3, target=(F(0),) * 3, up=(F(0), F(1), F(0)), fov=F(0)), res=[640, 480],
+    )
+    _pbrt_file(path, acc, st)
+    if not acc.order:
+        raise LoadError("pbrt: scene has no shapes")
+    res = tuple(st["res"])
+    cam = st["cam"]
+    camera = dict(position=tuple(cam["position"]), target=tuple(cam["target"]), up=tuple(cam["up"]), fov_axis=abi.FOV_Y if res[1] < res[0] else abi.FOV_X, fov_degrees=float(cam["fov"]))
+    return acc.finish(split_method, max_shapes_in_node, camera, res, os.path.basename(path)), camera, res
+
+
+def _pbrt_file(path, acc, st):
+    with open(path, "r", encoding="utf-8", newline="") as f:
+        lx = _Lexer(f.read())
+    parent = os.path.dirname(path) or "."
+
+    def nxt():
+        if st["fetched"] is not None:
+            t, st["fetched"] = st["fetched"], None
+            return t
+        return lx.next()
+
+    def want(kind):
+        t = nxt()
+        if t[0] != kind:
+            raise LoadError(f"UnexpectedToken {t}")
+        return t[1]
+
+    def numbers(single_ok, width):
+        t = nxt()
+        if t[0] == "num" and single_ok:
+            return [t[1]]
+        if t[0] != "[":
+            raise LoadError(f"UnexpectedToken {t}")
+        out = []
+        while True:
+            t = nxt()
+            if t[0] == "]":
+                return out
+            if t[0] != "num":
+                raise LoadError(f"UnexpectedToken {t}")
+            out.append(t[1])
+            for _ in range(width - 1):
+                out.append(want("num"))
+
+    def strings():
+        t = nxt()
+        if t[0] == "str":
+            return [t[1]]
+        if t[0] != "[":
+            raise LoadError(f"UnexpectedToken {t}")
+        out = []
+        while True:
+            t = nxt()
+            if t[0] == "]":
+                return out
+            if t[0] != "str":
+                raise LoadError(f"UnexpectedToken {t}")
+            out.append(t[1])
+
+    def vecs(vals, w):
+        return [tuple(F(x) for x in vals[k : k + w]) for k in range(0, len(vals), w)]
+
+    def param_set():
+        ps = _Params()
+        while True:
+            t = nxt()
+            if t[0] != "str":
+                st["fetched"] = t
+                return ps
+            w = t[1].split()
+            if len(w) != 2:
+                raise LoadError(f"UnexpectedToken {t[1]}")
+            ty, name = w
+            if ty == "bool":
+                vals = strings()
+                if any(v not in ("true", "false") for v in vals):
+                    raise LoadError("UnexpectedToken")
+                ps.add("bool", name, [v == "true" for v in vals])
+            elif ty == "float":
+                if name == "uv":
+                    ps.add("uv", name, vecs(numbers(False, 2), 2))
+                else:
+                    ps.add("float", name, [F(v) for v in numbers(True, 1)])
+            elif ty == "integer":
+                ps.add("int", name, [_sat_i32(v) for v in numbers(True, 1)])
+            elif ty in ("string", "texture"):
+                ps.add("string", name, strings())
+            elif ty in ("color", "rgb"):
+                ps.add("spectrum", name, vecs(numbers(False, 3), 3))
+            elif ty == "spectrum":
+                t2 = nxt()
+                if t2[0] == "str":
+                    vals = []
+                    with open(os.path.join(parent, t2[1])) as sf:
+                        for l in sf.read().split("\n"):
+                            vals += [parse_f32(x) for x in l.split("#")[0].split()]
+                else:
+                    st["fetched"] = t2
+                    vals = [F(v) for v in numbers(True, 1)]
+                if not vals or len(vals) % 2:
+                    raise LoadError("spectrum needs pairs")
+                ps.add("spectrum", name, [sampled_spectrum_into_rgb(vals[0::2], vals[1::2])])
+            elif ty == "point":
+                ps.add("point", name, vecs(numbers(False, 3), 3))
+            elif ty == "normal":
+                ps.add("normal", name, vecs(numbers(False, 3), 3))
+            elif ty == "blackbody":
+                numbers(True, 1)
+            else:
+                raise LoadError(f"UnknownParamType {ty} {name}")
+
+    try:
+        while True:
+            t = nxt()
+            if t[0] != "id":
+                raise LoadError(f"UnimplementedToken {t}")
+            d = t[1]
+            if d == "ActiveTransform":
+                a = nxt()
+                if a == ("id", "All") or a == ("id", "StartTime"):
+                    st["start"] = True
+                elif a == ("id", "EndTime"):
+                    st["start"] = False
+                else:
+                    raise LoadError(f"UnexpectedToken {a}")
+            elif d in ("AreaLightSource", "Integrator", "Sampler"):
+                want("str")
+                param_set()
+            elif d == "AttributeBegin":
+                st["gs_stack"].append(st["material"])
+                st["xf_stack"].append(st["xf"])
+                st["atb_stack"].append(st["start"])
+            elif d == "AttributeEnd":
+                if st["gs_stack"]:
+                    st["material"] = st["gs_stack"].pop()
+                    st["xf"] = st["xf_stack"].pop()
+                    st["start"] = st["atb_stack"].pop()
+            elif d == "Camera":
+                if want("str") != "perspective":
+                    raise LoadError("Only perspective camera is supported")
+                st["cam"]["fov"] = param_set().one("float", "fov", F(45.0))
+            elif d == "Film":
+                want("str")
+                ps = param_set()
+                st["res"] = [ps.one("int", "xresolution", 640) & 0xFFFF, ps.one("int", "yresolution", 480) & 0xFFFF]
+            elif d == "Include":
+                _pbrt_file(os.path.join(parent, want("str")), acc, st)
+            elif d == "LightSource":
+                ty = want("str")
+                ps = param_set()
+                ones = (F(1),) * 3
+                if ty == "infinite":
+                    acc.background = ps.one("spectrum", "L", ones)
+                elif ty == "distant":
+                    L = ps.one("spectrum", "L", ones)
+                    if any(c != 0 for c in L):
+                        fr = np.array(ps.one("point", "from", (F(0),) * 3), F)
+                        to = np.array(ps.one("point", "to", (F(0), F(0), F(1))), F)
+                        acc.lights.append(("distant", normalized(fr - to), L))
+                elif ty == "point":
+                    I = ps.one("spectrum", "I", ones)
+                    if any(c != 0 for c in I):
+                        acc.lights.append(("point", translation(ps.one("point", "from", (F(0),) * 3)), I))
+            elif d == "LookAt":
+                if st["start"]:
+                    cam = st["cam"]
+                    cam["position"] = (F(want("num")), F(want("num")), F(want("num")))
+                    cam["target"] = (F(want("num")), F(want("num")), F(want("num")))
+                    cam["up"] = tuple(normalized([F(want("num")), F(want("num")), F(want("num"))]))
+            elif d == "NamedMaterial":
+                st["material"] = st["named"].get(want("str"), 0)
+            elif d == "Material":
+                ty = want("str")
+                acc.materials.append(_material(ty, param_set(), st["textures"]))
+                st["material"] = len(acc.materials) - 1
+            elif d == "MakeNamedMaterial":
+                name = want("str")
+                if want("str") != "string type":
+                    raise LoadError("UnknownParamType")
+                ty = want("str")
+                acc.materials.append(_material(ty, param_set(), st["textures"]))
+                st["named"][name] = len(acc.materials) - 1
+            elif d == "Rotate":
+                ang = F(want("num"))
+                axis = [F(want("num")), F(want("num")), F(want("num"))]
+                st["xf"] = st["xf"] * rotation(ang * RADS_PER_DEG, axis)
+            elif d == "Scale":
+                x, y, z = F(want("num")), F(want("num")), F(want("num"))
+                st["xf"] = st["xf"] * scale(x, y, z)
+            elif d == "Translate":
+                v = [F(want("num")), F(want("num")), F(want("num"))]
+                st["xf"] = st["xf"] * translation(v)
+            elif d == "Shape":
+                ty = want("str")
+                ps = param_set()
+                if ty == "sphere":
+                    acc.order.append(("s", len(acc.spheres)))
+                    acc.spheres.append(dict(o2w=st["xf"].m.copy(), w2o=st["xf"].mi.copy(), radius=float(ps.one("float", "radius", F(1.0))), material=st["material"]))
+                elif ty == "trianglemesh":
+                    idx = [i & 0xFFFFFFFF for i in ps.many("int", "indices")]
+                    if len(idx) < 3 or len(idx) % 3:
+                        continue
+                    P, N, UV = ps.many("point", "P"), ps.many("normal", "N"), ps.many("uv", "uv")
+                    if max(idx) >= len(P) or (N and len(N) != len(P)) or (UV and len(UV) != len(P)):
+                        raise LoadError("trianglemesh: inconsistent counts")  # reference: index panic
+                    acc.add_mesh(st["xf"], idx, P, N, UV, st["material"])
+                elif ty == "plymesh":
+                    fn = ps.one("string", "filename", "")
+                    if not fn:
+                        raise LoadError("Empty PLY filename")
+                    _ply_mesh(acc, os.path.join(parent, fn), st["xf"], st["material"])
+            elif d == "Texture":
+                name, tt, cls = want("str"), want("str"), want("str")
+                ps = param_set()
+                if tt == "spectrum" and cls == "imagemap":
+                    if not ps.one("string", "filename", ""):
+                        raise LoadError(f"missing file for texture '{name}'")
+                    st["textures"].add(name)
+            elif d == "TransformBegin":
+                st["xf_stack"].append(st["xf"])
+            elif d == "TransformEnd":
+                if st["gs_stack"]:
+                    st["material"] = st["gs_stack"].pop()
+            elif d == "WorldBegin":
+                st["xf"] = Xf()
+            elif d == "WorldEnd":
+                pass
+            else:
+                raise LoadError(f"UnimplementedToken {d}")
+    except _Eof:
+        return

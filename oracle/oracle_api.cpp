@@ -130,6 +130,18 @@ int orc_scene_create(const orc_scene_desc* d, orc_scene** out) {
         delete s;
         return 2;
     }
+    if (d->shape_order) {
+        std::vector<Shape> ordered;
+        ordered.reserve(shapes.size());
+        for (size_t i = 0; i < shapes.size(); ++i) {
+            if (d->shape_order[i] >= shapes.size()) {
+                delete s;
+                return 4;
+            }
+            ordered.push_back(shapes[d->shape_order[i]]);
+        }
+        shapes.swap(ordered);
+    }
     bool ok = sc.bvh.build(&sc.geom, shapes, d->max_shapes_in_node, (int)d->split_method);
     if (!ok) {
         delete s;

@@ -67,6 +67,9 @@ typedef struct orc_scene_desc {
     float background[3];
     uint32_t split_method; /* 0 SAH, 1 Middle, 2 EqualCounts */
     uint32_t max_shapes_in_node;
+    /* order of Scene.shapes as handed to BoundingVolumeHierarchy::new (the pbrt loader keeps
+     * file order, pbrt/mod.rs:807-822); ids: triangles first, then spheres.  NULL = natural */
+    const uint32_t* shape_order;
 } orc_scene_desc;
 
 typedef struct orc_camera {

@@ -1,0 +1,193 @@
+"""Generators for the PLY / pbrt-v3 files the loader tests read (the reference ships
+no sample scenes; these are synthetic inputs written at test time)."""
+import os
+import struct
+
+CUBE_V = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 2), (1, 0, 2), (1, 1, 2), (0, 1, 2)]
+CUBE_F = [(0, 3, 2, 1), (4, 5, 6, 7), (0, 1, 5, 4), (1, 2, 6, 5), (2, 3, 7, 6), (3, 0, 4, 7)]
+
+
+def write_ascii_ply(path, verts=CUBE_V, faces=CUBE_F, index_name="vertex_indices", index_type="int", fmt="{:.9g}", scale=1.0):
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment synthetic\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n" % len(verts))
+        f.write("element face %d\nproperty list uchar %s %s\nend_header\n" % (len(faces), index_type, index_name))
+        for v in verts:
+            f.write(" ".join(fmt.format(c * scale) for c in v) + "\n")
+        for fc in faces:
+            f.write("%d %s\n" % (len(fc), " ".join(map(str, fc))))
+
+
+def write_binary_ply(path, endian="<", verts=CUBE_V, faces=CUBE_F, normals=True, uvs=True, extra=True):
+    """binary cube with optional normals / uv and properties the loader must skip
+    (a double, a uchar, a per-face int)."""
+    name = "binary_little_endian" if endian == "<" else "binary_big_endian"
+    h = "ply\nformat %s 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n" % (name, len(verts))
+    if normals:
+        h += "property float nx\nproperty float ny\nproperty float nz\n"
+    if extra:
+        h += "property double quality\n"
+    if uvs:
+        h += "property float u\nproperty float v\n"
+    if extra:
+        h += "property uchar red\n"
+    h += "element face %d\nproperty list uchar uint vertex_index\n" % len(faces)
+    if extra:
+        h += "property int flags\n"
+    h += "end_header\n"
+    b = h.encode()
+    for i, v in enumerate(verts):
+        b += struct.pack(endian + "3f", *[c * 0.3 + 0.01 * i for c in v])
+        if normals:
+            n = [c * 2 - 1 for c in v]
+            l = sum(c * c for c in n) ** 0.5
+            b += struct.pack(endian + "3f", *[c / l for c in n])
+        if extra:
+            b += struct.pack(endian + "d", i * 0.5)
+        if uvs:
+            b += struct.pack(endian + "2f", v[0] * 0.5, v[1] * 0.25)
+        if extra:
+            b += struct.pack(endian + "B", i)
+    for fc in faces:
+        b += struct.pack(endian + "B%dI" % len(fc), len(fc), *fc)
+        if extra:
+            b += struct.pack(endian + "i", 7)
+    with open(path, "wb") as f:
+        f.write(b)
+
+
+def uv_sphere(nu, nv, r=1.0):
+    import math
+
+    verts, faces = [], []
+    for j in range(nv + 1):
+        th = math.pi * j / nv
+        for i in range(nu):
+            ph = 2 * math.pi * i / nu
+            verts.append((r * math.sin(th) * math.cos(ph), r * math.sin(th) * math.sin(ph), r * math.cos(th)))
+    for j in range(nv):
+        for i in range(nu):
+            a, b = j * nu + i, j * nu + (i + 1) % nu
+            faces.append((a, b, b + nu, a + nu))
+    return verts, faces
+
+
+SCENE_PBRT = """# synthetic test scene: every directive the reference's loader implements
+LookAt 3 4 1.5  .5 .5 0  0 0 1
+Camera "perspective" "float fov" [ 39.5 ]
+Sampler "halton" "integer pixelsamples" 16
+Integrator "path" "integer maxdepth" [5]
+Film "image" "integer xresolution" [96] "integer yresolution" [64] "string filename" "out.exr"
+WorldBegin
+LightSource "infinite" "rgb L" [0.1 0.2 0.3]
+LightSource "distant" "point from" [1 2 3] "point to" [0 0 0] "rgb L" [3 3 2.5]
+AttributeBegin
+  Translate 0 0 4.5
+  AreaLightSource "diffuse" "rgb L" [1 1 1]
+  LightSource "point" "color I" [40 41 42] "point from" [0.25 0.5 0.125]
+  LightSource "point" "color I" [0 0 0]
+  LightSource "spot" "color I" [1 1 1]
+AttributeEnd
+MakeNamedMaterial "shiny" "string type" "metal" "float roughness" 0.05
+MakeNamedMaterial "cu2" "string type" "metal" "spectrum eta" [400 1.1 500 1.2 600 0.9 700 0.3] "rgb k" [3 2.5 2] "bool remaproughness" "false"
+MakeNamedMaterial "cu3" "string type" "metal" "spectrum eta" "geo/eta.spd" "blackbody k" [6500 1]
+MakeNamedMaterial "glassy" "string type" "glass" "float eta" 1.33 "rgb Kt" [.9 .95 1]
+Material "matte" "rgb Kd" [.6 .5 .4] "float sigma" 20
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-5 -5 0 5 -5 0 5 5 0 -5 5 0]
+   "normal N" [0 0 1 0 0 1 0 0 1 0 0 1] "float uv" [0 0 1 0 1 1 0 1]
+AttributeBegin
+  NamedMaterial "shiny"
+  Translate 1 0.5 0.75
+  Rotate 30 0 1 1
+  Scale 0.75 0.75 -0.75
+  Shape "sphere" "float radius" 1.0
+AttributeEnd
+AttributeBegin
+  NamedMaterial "glassy"
+  TransformBegin
+  Translate -1.5 0.25 0.5
+  Shape "sphere" "float radius" 0.5
+  TransformEnd
+AttributeEnd
+AttributeBegin
+  Material "glossy" "rgb Rs" [.3 .7 .2] "float roughness" 0.2
+  Translate -0.5 -1.5 0.0
+  Rotate -40 0 0 1
+  Include "geo/inc.pbrt"
+AttributeEnd
+NamedMaterial "nope"
+Shape "cone"
+Shape "trianglemesh" "integer indices" [0 1] "point P" [0 0 0 1 1 1 2 2 2]
+AttributeBegin
+NamedMaterial "cu2"
+Translate 2 -2 0
+Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 1 ]
+NamedMaterial "cu3"
+Shape "trianglemesh" "integer indices" [0 2 1] "point P" [0 0 1 1 0 1 0 1 2 ]
+AttributeEnd
+WorldEnd
+"""
+
+INC_PBRT = """# included from scene.pbrt
+Shape "plymesh" "string filename" "cube_n.ply"
+Material "plastic"
+Shape "plymesh" "string filename" "../cube.ply"
+ActiveTransform All
+"""
+
+ETA_SPD = "# wavelength value\n400 1.1\n500 1.25 # trailing\n\n600 0.85\n700 0.35\n"
+
+
+def write_scene(dirname):
+    """scene.pbrt + geo/{inc.pbrt,cube_n.ply,eta.spd} + cube.ply ; returns the .pbrt path."""
+    os.makedirs(os.path.join(dirname, "geo"), exist_ok=True)
+    write_ascii_ply(os.path.join(dirname, "cube.ply"))
+    write_binary_ply(os.path.join(dirname, "geo", "cube_n.ply"))
+    for name, text in (("scene.pbrt", SCENE_PBRT), ("geo/inc.pbrt", INC_PBRT), ("geo/eta.spd", ETA_SPD)):
+        with open(os.path.join(dirname, name), "w") as f:
+            f.write(text)
+    return os.path.join(dirname, "scene.pbrt")
+
+
+def write_render_scene(dirname, nu=24, nv=12):
+    """A small closed scene for render parity: floor + tessellated ply spheres + analytic
+    spheres, all material kinds, point + distant lights + background."""
+    os.makedirs(dirname, exist_ok=True)
+    v, f = uv_sphere(nu, nv, 0.8)
+    write_ascii_ply(os.path.join(dirname, "ball.ply"), v, f, index_name="vertex_index", index_type="uint")
+    text = """LookAt 0 -6 2.5  0 0 0.8  0 0 1
+Camera "perspective" "float fov" 42
+Film "image" "integer xresolution" [80] "integer yresolution" [60]
+WorldBegin
+LightSource "infinite" "rgb L" [0.25 0.3 0.4]
+LightSource "distant" "point from" [2 -3 4] "point to" [0 0 0] "rgb L" [2 2 1.8]
+LightSource "point" "rgb I" [30 25 20] "point from" [-2 -1 4]
+Material "matte" "rgb Kd" [.55 .5 .45]
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 -6 0 6 -6 0 6 6 0 -6 6 0]
+AttributeBegin
+  Material "matte" "rgb Kd" [.7 .3 .3] "float sigma" 2000
+  Translate -1.8 0.5 0.8
+  Shape "plymesh" "string filename" "ball.ply"
+AttributeEnd
+AttributeBegin
+  Material "metal" "float roughness" 0.2 "rgb eta" [0.2 0.9 1.1] "rgb k" [3.9 2.4 2.2]
+  Translate 0 1.5 0.8
+  Rotate 25 0 0 1
+  Scale 1 1 1.2
+  Shape "plymesh" "string filename" "ball.ply"
+AttributeEnd
+AttributeBegin
+  Material "glass" "float eta" 1.5
+  Translate 1.7 -0.5 0.7
+  Shape "sphere" "float radius" 0.7
+AttributeEnd
+AttributeBegin
+  Material "glossy" "rgb Rs" [.4 .6 .3] "float roughness" 0.3
+  Translate -0.2 -1.6 0.45
+  Shape "sphere" "float radius" 0.45
+AttributeEnd
+WorldEnd
+"""
+    p = os.path.join(dirname, "render.pbrt")
+    with open(p, "w") as fh:
+        fh.write(text)
+    return p

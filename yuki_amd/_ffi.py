@@ -96,6 +96,11 @@ SYMBOLS = {
     "yk_bsdf_eval": (C.c_int, [vp, C.POINTER(abi.MaterialDesc), C.c_size_t] + [vp] * 6),
     "yk_bsdf_sample": (C.c_int, [vp, C.POINTER(abi.MaterialDesc), C.c_size_t] + [vp] * 6),
     "yk_sizeof": (C.c_size_t, [C.c_int]),
+    "yk_load_ply": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+    "yk_load_pbrt": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+    "yk_loaded_scene_get": (C.c_int, [vp, C.POINTER(abi.SceneDesc), C.POINTER(abi.CameraParams), C.POINTER(C.c_uint16)]),
+    "yk_loaded_scene_destroy": (None, [vp]),
+    "yk_loader_last_error": (C.c_char_p, []),
 }
 
 

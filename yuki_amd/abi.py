@@ -65,6 +65,7 @@ class SceneDesc(C.Structure):
         ("background", C.c_float * 3),
         ("split_method", C.c_uint32),
         ("max_shapes_in_node", C.c_uint32),
+        ("shape_order", u32p),
     ]
 
 

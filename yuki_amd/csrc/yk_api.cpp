@@ -383,9 +383,25 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         }
         sb[(size_t)d->n_triangles + i] = b;
     }
+    if (d->shape_order) {  // the caller's Scene.shapes order (a permutation of all shapes)
+        std::vector<uint8_t> seen(sb.size(), 0);
+        std::vector<ShapeBounds> ordered(sb.size());
+        for (size_t i = 0; i < sb.size(); ++i) {
+            const uint32_t src = d->shape_order[i];
+            if (src >= sb.size() || seen[src]) {
+                delete s;
+                return fail(ctx, YK_ERR_INVALID_ARGUMENT, "shape_order is not a permutation of the shapes");
+            }
+            seen[src] = 1;
+            ordered[i] = sb[src];
+        }
+        sb.swap(ordered);
+    }
     double t0 = now_seconds();
     build_bvh(sb, d->max_shapes_in_node, d->split_method, s->bvh);
     s->info.build_seconds = now_seconds() - t0;
+    if (d->shape_order)  // leaf order -> position in Scene.shapes -> source shape
+        for (uint32_t& o : s->bvh.shape_order) o = d->shape_order[o];
     if (s->bvh.split_failed || s->bvh.nodes.empty()) {
         delete s;
         return fail(ctx, YK_ERR_BVH_BUILD, "BVH split failed (reference: assert_ne!(mid, start))");

@@ -88,6 +88,9 @@ class SceneData:
     max_shapes_in_node: int = 1
     camera: dict = None  # position, target, up, fov_axis, fov_degrees
     name: str = ""
+    shape_order: np.ndarray = None  # Scene.shapes order (ids: triangles, then spheres); None = natural
+    film_res: tuple = None  # FilmSettings.res when the scene came from a loader
+    light_structs: list = None  # ready abi.LightDesc values (loaders); overrides `lights`
 
     @property
     def n_triangles(self):
@@ -97,6 +100,11 @@ class SceneData:
         """Build LightDesc structs through `factory` — an object exposing
         make_rect_light / make_spot_light / make_point_light (the HIP library's
         host helpers; the tests pass the checker.s own)."""
+        if self.light_structs is not None:
+            arr = (abi.LightDesc * max(1, len(self.light_structs)))()
+            for k, l in enumerate(self.light_structs):
+                C.memmove(C.byref(arr[k]), C.byref(l), C.sizeof(abi.LightDesc))
+            return arr
         arr = (abi.LightDesc * max(1, len(self.lights)))()
         for k, l in enumerate(self.lights):
             if l["kind"] == "rect":
@@ -160,11 +168,13 @@ class SceneData:
         d.materials = C.cast(mats, C.POINTER(abi.MaterialDesc))
         lights = self.light_descs(factory)
         keep["lights"] = lights
-        d.n_lights = len(self.lights)
+        d.n_lights = len(self.lights) if self.light_structs is None else len(self.light_structs)
         d.lights = C.cast(lights, C.POINTER(abi.LightDesc))
         d.background = abi.f3(self.background)
         d.split_method = self.split_method
         d.max_shapes_in_node = self.max_shapes_in_node
+        keep["shape_order"] = None if self.shape_order is None else np.ascontiguousarray(self.shape_order, dtype=np.uint32)
+        d.shape_order = abi.ptr(keep["shape_order"], abi.u32p)
         return d, keep
 
 
