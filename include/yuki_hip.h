@@ -40,7 +40,7 @@ typedef enum yk_status {
     YK_ERR_NO_DEVICE = 2,        /* HIP runtime / device unavailable */
     YK_ERR_DEVICE = 3,           /* a HIP call failed; see yk_last_error */
     YK_ERR_OUT_OF_MEMORY = 4,
-    YK_ERR_UNSUPPORTED = 5,      /* e.g. spheres / Whitted on the device path */
+    YK_ERR_UNSUPPORTED = 5,      /* e.g. Whitted on the device path, unsupported file content */
     YK_ERR_BVH_BUILD = 6,        /* reference: assert_ne!(mid,start) bvh.rs:368 */
     YK_ERR_CANCELLED = 7,        /* early_termination_predicate returned true */
     YK_ERR_STACK_OVERFLOW = 8    /* traversal stack > 64, reference: assert bvh.rs:174 */

@@ -67,7 +67,7 @@ def uv_sphere(nu, nv, r=1.0):
     for j in range(nv):
         for i in range(nu):
             a, b = j * nu + i, j * nu + (i + 1) % nu
-            faces.append((a, b, b + nu, a + nu))
+            faces.append((a, a + nu, b + nu, b))  # outward winding
     return verts, faces
 
 
