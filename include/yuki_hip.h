@@ -69,8 +69,18 @@ typedef struct yk_material_desc {
     float a[3];     /* matte Kd | glass R | metal eta | glossy Rs */
     float b[3];     /*          | glass T | metal k   |           */
     float c;        /* matte sigma (radians) | glass eta | metal/glossy roughness */
-    uint32_t flags; /* bit0: remap_roughness */
+    uint32_t flags; /* bit0: remap_roughness ; bit1: matte Kd comes from textures[a_texture] */
+    uint32_t a_texture; /* ImageTexture index when bit1 is set (scene/pbrt/mod.rs:887-902) */
 } yk_material_desc;
+#define YK_MAT_FLAG_REMAP 1u
+#define YK_MAT_FLAG_TEXTURED_A 2u
+
+/* textures/image_texture.rs:49-56 `ImageTexture<Spectrum<f32>>`: row-major RGB, row 0 = top
+ * row of the image file; evaluated point-sampled, repeat, v flipped (:81-111) */
+typedef struct yk_texture_desc {
+    uint32_t width, height;
+    const float* rgb; /* 3 * width * height */
+} yk_texture_desc;
 
 /* lights/{point,spot,distant,rectangular}_light.rs — build with yk_make_*_light */
 typedef enum yk_light_kind { YK_LIGHT_POINT = 0, YK_LIGHT_SPOT = 1, YK_LIGHT_DISTANT = 2, YK_LIGHT_RECT = 3 } yk_light_kind;
@@ -113,6 +123,8 @@ typedef struct yk_scene_desc {
      * pbrt loader fills in file order): n_triangles + n_spheres entries, entry < n_triangles
      * = that triangle, otherwise sphere (entry - n_triangles).  NULL = triangles, then spheres. */
     const uint32_t* shape_order;
+    uint32_t n_textures;
+    const yk_texture_desc* textures;
 } yk_scene_desc;
 
 /* camera.rs:19-22 `Camera` = two Transforms */
@@ -292,10 +304,17 @@ size_t yk_sizeof(int what);
  *                 implements: perspective Camera, Film resolution, LookAt, Translate/Scale/
  *                 Rotate, Attribute/Transform blocks, Include, (Make)NamedMaterial/Material
  *                 {matte,glass,glossy,metal}, LightSource {infinite,distant,point}, Shape
- *                 {sphere,trianglemesh,plymesh}; image textures are not supported yet.
+ *                 {sphere,trianglemesh,plymesh}, Texture "spectrum" "imagemap" (PNG) for matte Kd.
  * split_method / max_shapes_in_node are SceneLoadSettings (scene/mod.rs:25-39) and are
  * copied into the description.  Errors: where the reference returns LoadError or panics
  * the call returns non-zero and yk_loader_last_error() (thread-local) holds the reason. */
+/* ImageTexture::new(path) (textures/image_texture.rs:66-70,114-141): decode an image file
+ * into RGB f32 (u8 / 255, u16 / 65535, no gamma).  PNG only (the `image` crate's other
+ * formats return YK_ERR_UNSUPPORTED); gray / gray-alpha files are the reference's
+ * "Unsupported image format".  out->rgb is owned by the library: yk_image_texture_free. */
+yk_status yk_image_texture_load(const char* path, yk_texture_desc* out);
+void yk_image_texture_free(yk_texture_desc* tex);
+
 typedef struct yk_loaded_scene yk_loaded_scene;
 yk_status yk_load_ply(const char* path, uint32_t split_method, uint32_t max_shapes_in_node, yk_loaded_scene** out);
 yk_status yk_load_pbrt(const char* path, uint32_t split_method, uint32_t max_shapes_in_node, yk_loaded_scene** out);

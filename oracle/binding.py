@@ -87,6 +87,8 @@ def lib():
     L.orc_bsdf_eval.restype = None
     L.orc_bsdf_sample.argtypes = [C.POINTER(abi.MaterialDesc)] + [vp] * 6
     L.orc_bsdf_sample.restype = None
+    L.orc_texture_eval.argtypes = [C.POINTER(abi.TextureDesc), C.c_size_t, vp, vp]
+    L.orc_texture_eval.restype = None
     L.orc_sizeof.argtypes = [C.c_int]
     L.orc_sizeof.restype = C.c_size_t
     _LIB = L
@@ -218,3 +220,13 @@ def detile(tiles, rgb, res):
         film[t["y0"] : t["y1"], t["x0"] : t["x1"]] = rgb[off : off + w * h].reshape(h, w, 3)
         off += w * h
     return film
+
+
+def texture_eval(tex, uv):
+    """ImageTexture::evaluate of the C++ restatement at (n, 2) uv pairs -> (n, 3)."""
+    tex = np.ascontiguousarray(tex, dtype=np.float32)
+    uv = np.ascontiguousarray(uv, dtype=np.float32)
+    d = abi.TextureDesc(tex.shape[1], tex.shape[0], abi.ptr(tex, abi.f32p))
+    out = np.zeros((uv.shape[0], 3), dtype=np.float32)
+    lib().orc_texture_eval(C.byref(d), uv.shape[0], _p(uv), _p(out))
+    return out

@@ -26,7 +26,7 @@ import numpy as np
 from yuki_amd import abi
 from yuki_amd.scenes import SceneData
 
-from . import binding
+from . import binding, images
 
 F = np.float32
 _libc = C.CDLL(None)
@@ -116,6 +116,7 @@ class _Accum:
         self.points, self.normals, self.uvs = [], [], []
         self.indices, self.tri_mesh, self.tri_material = [], [], []
         self.meshes, self.spheres, self.materials, self.lights = [], [], [], []
+        self.textures = []
         self.order = []  # ('t', tri id) | ('s', sphere id) in Scene.shapes order
         self.background = (F(0), F(0), F(0))
         self.nv = 0
@@ -171,6 +172,7 @@ class _Accum:
             name=name,
             shape_order=order,
             film_res=film_res,
+            textures=self.textures,
         )
         sd.light_structs = lights
         return sd
@@ -505,9 +507,11 @@ def _material(kind, ps, textures):
         return dict(kind=abi.MAT_GLOSSY, a=ps.one("spectrum", "Rs", half), b=(0, 0, 0), c=ps.one("float", "roughness", F(0.5)), remap=False)
     if kind == "matte":
         tex = ps.one("string", "Kd", "")
-        if tex:
-            raise LoadError(f"Texture '{tex}' " + ("unsupported" if tex in textures else "not found"))
+        if tex and tex not in textures:
+            raise LoadError(f"Texture '{tex}' not found")
         sigma = ps.one("float", "sigma", F(0)) * RADS_PER_DEG
+        if tex:
+            return dict(kind=abi.MAT_MATTE, a=(0, 0, 0), b=(0, 0, 0), c=sigma * RADS_PER_DEG, remap=False, tex=textures[tex])
         return dict(kind=abi.MAT_MATTE, a=ps.one("spectrum", "Kd", half), b=(0, 0, 0), c=sigma * RADS_PER_DEG, remap=False)
     if kind == "metal":
         lam, n, k = _copper()
@@ -523,7 +527,7 @@ def load_pbrt(path, split_method=abi.SPLIT_SAH, max_shapes_in_node=1):
     acc = _Accum()
     acc.materials.append(_material("matte", _Params(), {}))  # default_material
     st = dict(
-        xf=Xf(), xf_stack=[], gs_stack=[], atb_stack=[], named={}, textures=set(), material=0, start=True, fetched=None,
+        xf=Xf(), xf_stack=[], gs_stack=[], atb_stack=[], named={}, textures={}, material=0, start=True, fetched=None,
         cam=dict(position=(F(0),) * 3, target=(F(0),) * 3, up=(F(0), F(1), F(0)), fov=F(0)), res=[640, 480],
     )
     _pbrt_file(path, acc, st)
@@ -740,9 +744,14 @@ def _pbrt_file(path, acc, st):
                 name, tt, cls = want("str"), want("str"), want("str")
                 ps = param_set()
                 if tt == "spectrum" and cls == "imagemap":
-                    if not ps.one("string", "filename", ""):
+                    fn = ps.one("string", "filename", "")
+                    if not fn:
                         raise LoadError(f"missing file for texture '{name}'")
-                    st["textures"].add(name)
+                    try:
+                        acc.textures.append(images.load_png(os.path.join(parent, fn)))
+                    except images.ImageError as e:
+                        raise LoadError(str(e))
+                    st["textures"][name] = len(acc.textures) - 1
             elif d == "TransformBegin":
                 st["xf_stack"].append(st["xf"])
             elif d == "TransformEnd":

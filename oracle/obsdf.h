@@ -4,6 +4,7 @@
 // yuki/src/materials/bsdfs/*.rs, plus the sampling helpers of
 // yuki/src/sampling/mod.rs:62-87.  Parity unpinned by the reference.
 #pragma once
+#include <vector>
 #include "olibm.h"
 #include "omath.h"
 #include "oshapes.h"
@@ -332,6 +333,32 @@ struct Material {
     Spectrumf a, b;  // matte: a=Kd ; glass: a=R,b=T ; metal: a=eta,b=k ; glossy: a=Rs
     float c;         // matte: sigma (radians) ; glass: eta ; metal/glossy: roughness
     bool remap_roughness;
+    int a_texture = -1;  // matte: Kd is an ImageTexture (index into the scene's textures) when >= 0
+};
+
+// textures/image_texture.rs:49-111
+struct ImageTexture {
+    std::vector<Spectrumf> data;
+    size_t width = 0, height = 0;
+    // `f as usize`: saturating, NaN -> 0
+    static size_t as_usize(float f) {
+        if (!(f > 0.0f)) return 0;
+        if (f >= 18446744073709551616.0f) return ~(size_t)0;
+        return (size_t)f;
+    }
+    Spectrumf evaluate(const SurfaceInteraction& si) const {
+        Point2f st = si.uv;
+        // Repeat
+        st.x = st.x - std::trunc(st.x);  // f32::fract
+        if (st.x < 0.0f) st.x = 1.0f + st.x;
+        st.y = st.y - std::trunc(st.y);
+        if (st.y < 0.0f) st.y = 1.0f + st.y;
+        // Flip y
+        st.y = 1.0f - st.y;
+        st.x = st.x * (float)width - 0.5f;
+        st.y = st.y * (float)height - 0.5f;
+        return data.at(as_usize(st.y) * width + as_usize(st.x));  // the reference panics when out of range
+    }
 };
 
 // bsdfs/mod.rs:74-223
@@ -422,11 +449,11 @@ struct Bsdf {
 
 // Material::compute_scattering_functions — matte.rs:22-40, glass.rs:27-45,
 // metal.rs:34-61, glossy.rs:32-58
-inline Bsdf compute_scattering_functions(const Material& m, const SurfaceInteraction& si) {
+inline Bsdf compute_scattering_functions(const Material& m, const SurfaceInteraction& si, const std::vector<ImageTexture>* textures = nullptr) {
     Bsdf bsdf(si);
     switch (m.kind) {
         case MAT_MATTE: {
-            Spectrumf reflectance = m.a;
+            Spectrumf reflectance = (m.a_texture >= 0 && textures) ? textures->at((size_t)m.a_texture).evaluate(si) : m.a;
             float sigma = m.c;
             if (!reflectance.is_black()) {
                 Bxdf b;

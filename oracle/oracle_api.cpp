@@ -79,7 +79,20 @@ int orc_scene_create(const orc_scene_desc* d, orc_scene** out) {
         m.b = sp(d->materials[i].b);
         m.c = d->materials[i].c;
         m.remap_roughness = (d->materials[i].flags & 1u) != 0;
+        m.a_texture = (m.kind == MAT_MATTE && (d->materials[i].flags & 2u)) ? (int)d->materials[i].a_texture : -1;
+        if (m.a_texture >= (int)d->n_textures) {
+            delete s;
+            return 5;
+        }
         sc.materials.push_back(m);
+    }
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        ImageTexture t;
+        t.width = d->textures[i].width;
+        t.height = d->textures[i].height;
+        const float* q = d->textures[i].rgb;
+        for (size_t k = 0; k < t.width * t.height; ++k) t.data.push_back(Spectrumf(q[3 * k], q[3 * k + 1], q[3 * k + 2]));
+        sc.textures.push_back(t);
     }
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         const orc_light_desc& l = d->lights[i];
@@ -515,6 +528,21 @@ void orc_bsdf_sample(const orc_material_desc* m, const float* n_geom, const floa
     out[3] = s.f.r; out[4] = s.f.g; out[5] = s.f.b;
     out[6] = s.pdf;
     out[7] = (float)s.sample_type;
+}
+
+void orc_texture_eval(const orc_texture_desc* tex, size_t n, const float* uv, float* out_rgb) {
+    ImageTexture t;
+    t.width = tex->width;
+    t.height = tex->height;
+    for (size_t k = 0; k < t.width * t.height; ++k) t.data.push_back(Spectrumf(tex->rgb[3 * k], tex->rgb[3 * k + 1], tex->rgb[3 * k + 2]));
+    for (size_t i = 0; i < n; ++i) {
+        SurfaceInteraction si;
+        si.uv = Point2f(uv[2 * i], uv[2 * i + 1]);
+        Spectrumf c = t.evaluate(si);
+        out_rgb[3 * i] = c.r;
+        out_rgb[3 * i + 1] = c.g;
+        out_rgb[3 * i + 2] = c.b;
+    }
 }
 
 size_t orc_sizeof(int what) {

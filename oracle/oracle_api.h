@@ -32,8 +32,15 @@ typedef struct orc_material_desc {
     float a[3];      /* matte Kd | glass R | metal eta | glossy Rs */
     float b[3];      /*          | glass T | metal k   |           */
     float c;         /* matte sigma(rad) | glass eta | metal/glossy roughness */
-    uint32_t flags;  /* bit0: remap_roughness */
+    uint32_t flags;  /* bit0: remap_roughness ; bit1: matte Kd = textures[a_texture] */
+    uint32_t a_texture;
 } orc_material_desc;
+
+/* ImageTexture<Spectrum<f32>> (textures/image_texture.rs:49-56): row-major RGB, row 0 = top */
+typedef struct orc_texture_desc {
+    uint32_t width, height;
+    const float* rgb;
+} orc_texture_desc;
 
 typedef struct orc_light_desc {
     uint32_t kind;  /* 0 point, 1 spot, 2 distant, 3 rectangular */
@@ -70,6 +77,8 @@ typedef struct orc_scene_desc {
     /* order of Scene.shapes as handed to BoundingVolumeHierarchy::new (the pbrt loader keeps
      * file order, pbrt/mod.rs:807-822); ids: triangles first, then spheres.  NULL = natural */
     const uint32_t* shape_order;
+    uint32_t n_textures;
+    const orc_texture_desc* textures;
 } orc_scene_desc;
 
 typedef struct orc_camera {
@@ -186,6 +195,9 @@ void orc_bsdf_eval(const orc_material_desc* m, const float* n_geom, const float*
                    const float* wo, const float* wi, float* out_f);
 void orc_bsdf_sample(const orc_material_desc* m, const float* n_geom, const float* n_shading, const float* dpdu,
                      const float* wo, const float* u, float* out /* wi[3], f[3], pdf, type */);
+
+/* ImageTexture::evaluate at n uv pairs (KAT hook) */
+void orc_texture_eval(const orc_texture_desc* tex, size_t n, const float* uv, float* out_rgb);
 
 size_t orc_sizeof(int what);
 

@@ -125,6 +125,7 @@ struct Scene {
     BVH bvh;
     std::vector<Material> materials;
     std::vector<Light> lights;
+    std::vector<ImageTexture> textures;
     Spectrumf background;
     // owned copies of the caller's arrays
     std::vector<float> points, normals, uvs;
@@ -207,7 +208,7 @@ inline RadianceResult path_li(const IntegratorParams& prm, Rayf ray, const Scene
         }
         if (ir.has_hit) {
             const SurfaceInteraction& si = ir.hit.si;
-            Bsdf bsdf = compute_scattering_functions(scene.materials[ir.hit.shape->material], si);
+            Bsdf bsdf = compute_scattering_functions(scene.materials[ir.hit.shape->material], si, &scene.textures);
             Spectrumf radiance = direct_lighting(scene, si, bsdf, sampler, st);
             if (bounces == 0 || specular_bounce) radiance += beta * emitted_radiance(scene.lights, si, -ray.d);
             if (bounces > 0 && prm.has_clamp) radiance = radiance.smin(Spectrumf::ones() * prm.indirect_clamp);
@@ -252,7 +253,7 @@ inline RadianceResult whitted_li(const IntegratorParams& prm, Rayf ray, const Sc
         return out;
     }
     const SurfaceInteraction& si = ir.hit.si;
-    Bsdf bsdf = compute_scattering_functions(scene.materials[ir.hit.shape->material], si);
+    Bsdf bsdf = compute_scattering_functions(scene.materials[ir.hit.shape->material], si, &scene.textures);
     size_t ray_count = 1;
     Spectrumf sum_li = direct_lighting(scene, si, bsdf, sampler, st);
     if (depth == 0 || is_specular) sum_li += emitted_radiance(scene.lights, si, -ray.d);

@@ -191,3 +191,158 @@ WorldEnd
     with open(p, "w") as fh:
         fh.write(text)
     return p
+
+
+# ----------------------------------------------------------------------------- PNG
+def write_png(path, img, depth=8, alpha=False, palette=None, interlace=False, filters=(0, 1, 2, 3, 4), level=6, fixed=False, gray=False, trns=False):
+    """Minimal PNG encoder for test inputs.  img: (h, w, 3) integer array (values < 2**depth),
+    or (h, w) palette indices when `palette` ((n,3) uint8) is given.  Scanline filter types
+    cycle through `filters`."""
+    import zlib
+
+    import numpy as np
+
+    img = np.asarray(img)
+    h, w = img.shape[:2]
+    if palette is not None:
+        ctype, channels = 3, 1
+    elif gray:
+        ctype, channels = (4 if alpha else 0), (2 if alpha else 1)
+        img = img[..., :1]
+    else:
+        ctype, channels = (6 if alpha else 2), (4 if alpha else 3)
+    if alpha:
+        a = np.full(img.shape[:2] + (1,), (1 << depth) - 1 - 3, dtype=img.dtype)
+        img = np.concatenate([img.reshape(h, w, -1), a], axis=2)
+
+    def pack_rows(sub):
+        sh, sw = sub.shape[:2]
+        if palette is not None:
+            bits = ((sub.reshape(sh, sw, 1).astype(np.uint8) >> np.arange(depth - 1, -1, -1)) & 1).reshape(sh, sw * depth)
+            pad = (-bits.shape[1]) % 8
+            bits = np.pad(bits, ((0, 0), (0, pad)))
+            return np.packbits(bits.astype(np.uint8), axis=1)
+        if depth == 8:
+            return sub.reshape(sh, sw * channels).astype(np.uint8)
+        v = sub.reshape(sh, sw * channels).astype(np.uint16)
+        return np.stack([(v >> 8).astype(np.uint8), (v & 0xFF).astype(np.uint8)], axis=2).reshape(sh, -1)
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+
+    bpp = max(1, channels * depth // 8)
+    raw = bytearray()
+    fcount = 0
+
+    def emit(sub):
+        nonlocal fcount
+        rows = pack_rows(sub).astype(np.int64)
+        prev = np.zeros(rows.shape[1], dtype=np.int64)
+        for line in rows:
+            ft = filters[fcount % len(filters)]
+            fcount += 1
+            out = np.zeros_like(line)
+            for x in range(len(line)):
+                a = line[x - bpp] if x >= bpp else 0
+                b = prev[x]
+                c = prev[x - bpp] if x >= bpp else 0
+                pred = [0, a, b, (a + b) >> 1, paeth(a, b, c)][ft]
+                out[x] = (line[x] - pred) & 0xFF
+            raw.append(ft)
+            raw.extend(out.astype(np.uint8).tobytes())
+            prev = line
+
+    if interlace:
+        for x0, y0, dx, dy in [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]:
+            sub = img[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                emit(sub)
+    else:
+        emit(img)
+    if fixed:
+        co = zlib.compressobj(level, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        comp = co.compress(bytes(raw)) + co.flush()
+    else:
+        comp = zlib.compress(bytes(raw), level)
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0))
+    out += chunk(b"gAMA", struct.pack(">I", 45455))  # must be ignored
+    if palette is not None:
+        out += chunk(b"PLTE", np.asarray(palette, dtype=np.uint8).tobytes())
+    if trns:
+        out += chunk(b"tRNS", bytes([0, 128]) if palette is not None else struct.pack(">3H", 1, 2, 3))
+    half = len(comp) // 2
+    out += chunk(b"IDAT", comp[:half]) + chunk(b"IDAT", comp[half:]) + chunk(b"tEXt", b"Comment\0synthetic") + chunk(b"IEND", b"")
+    with open(path, "wb") as f:
+        f.write(out)
+
+
+def test_pattern(w, h, depth=8, seed=3):
+    """Deterministic colourful (h, w, 3) integer image with smooth and noisy regions."""
+    import numpy as np
+
+    y, x = np.mgrid[0:h, 0:w]
+    m = (1 << depth) - 1
+    r = (x * m) // max(1, w - 1)
+    g = (y * m) // max(1, h - 1)
+    b = ((x * 2654435761 + y * 40503 + seed * 97) >> 3) & m
+    chk = (((x // 4) + (y // 4)) & 1) * (m // 3)
+    return np.stack([r, (g + chk) & m, b], axis=2).astype(np.int64)
+
+
+TEXTURED_PBRT = """LookAt 0 -5 3  0 0 0.6  0 0 1
+Camera "perspective" "float fov" 45
+Film "image" "integer xresolution" [72] "integer yresolution" [54]
+WorldBegin
+LightSource "infinite" "rgb L" [0.35 0.35 0.4]
+LightSource "point" "rgb I" [40 38 35] "point from" [1 -2 5]
+Texture "checks" "spectrum" "imagemap" "string filename" "tex/checks.png"
+Texture "deep" "spectrum" "imagemap" "string filename" "tex/deep16.png"
+Texture "unused" "float" "scale" "float tex1" 2
+Material "matte" "texture Kd" "checks"
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 -4 0 4 -4 0 4 4 0 -4 4 0]
+   "float uv" [-1.25 -0.5 2.75 -0.5 2.75 3.5 -1.25 3.5]
+AttributeBegin
+  Material "matte" "texture Kd" "deep" "float sigma" 1500
+  Translate -1.2 0.2 0.8
+  Rotate 35 0 0 1
+  Shape "sphere" "float radius" 0.8
+AttributeEnd
+AttributeBegin
+  Material "matte" "texture Kd" "checks"
+  Translate 1.3 0.4 0.7
+  Shape "plymesh" "string filename" "ball.ply"
+AttributeEnd
+AttributeBegin
+  Texture "checks" "spectrum" "imagemap" "string filename" "tex/pal.png"
+  Material "matte" "texture Kd" "checks"
+  Translate 0.2 -1.6 0.5
+  Scale 0.5 0.5 -0.5
+  Shape "plymesh" "string filename" "ball.ply"
+AttributeEnd
+WorldEnd
+"""
+
+
+def write_textured_scene(dirname):
+    import numpy as np
+
+    os.makedirs(os.path.join(dirname, "tex"), exist_ok=True)
+    v, f = uv_sphere(20, 10, 0.7)
+    write_ascii_ply(os.path.join(dirname, "ball.ply"), v, f)
+    img = test_pattern(37, 23)
+    img[5:9, 7:20] = 0  # a black patch: matte adds no lobe there (matte.rs:31)
+    write_png(os.path.join(dirname, "tex", "checks.png"), img, alpha=True, filters=(4, 1, 3, 2, 0))
+    write_png(os.path.join(dirname, "tex", "deep16.png"), test_pattern(16, 16, depth=16), depth=16, interlace=True)
+    pal = np.array([[255, 40, 30], [20, 200, 60], [0, 0, 0], [250, 250, 240], [30, 60, 220]], dtype=np.uint8)
+    idx = (np.add.outer(np.arange(11), np.arange(13)) % 5).astype(np.uint8)
+    write_png(os.path.join(dirname, "tex", "pal.png"), idx, depth=4, palette=pal)
+    p = os.path.join(dirname, "textured.pbrt")
+    with open(p, "w") as fh:
+        fh.write(TEXTURED_PBRT)
+    return p

@@ -33,6 +33,10 @@ def assert_same_scene(want, got):
     for a, b in zip(want.materials, got.materials):
         assert a["kind"] == b["kind"] and _f3(a["a"]) == _f3(b["a"]) and _f3(a["b"]) == _f3(b["b"]), (a, b)
         assert np.float32(a["c"]).tobytes() == np.float32(b["c"]).tobytes() and bool(a["remap"]) == bool(b["remap"]), (a, b)
+        assert a.get("tex") == b.get("tex"), (a, b)
+    assert len(want.textures) == len(got.textures)
+    for a, b in zip(want.textures, got.textures):
+        assert _eq(np.asarray(a, np.float32), np.asarray(b, np.float32))
     assert len(want.spheres) == len(got.spheres)
     for a, b in zip(want.spheres, got.spheres):
         assert _eq(np.asarray(a["o2w"], np.float32), b["o2w"]) and _eq(np.asarray(a["w2o"], np.float32), b["w2o"])

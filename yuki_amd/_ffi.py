@@ -101,6 +101,8 @@ SYMBOLS = {
     "yk_loaded_scene_get": (C.c_int, [vp, C.POINTER(abi.SceneDesc), C.POINTER(abi.CameraParams), C.POINTER(C.c_uint16)]),
     "yk_loaded_scene_destroy": (None, [vp]),
     "yk_loader_last_error": (C.c_char_p, []),
+    "yk_image_texture_load": (C.c_int, [C.c_char_p, C.POINTER(abi.TextureDesc)]),
+    "yk_image_texture_free": (None, [C.POINTER(abi.TextureDesc)]),
 }
 
 

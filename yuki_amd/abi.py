@@ -26,7 +26,13 @@ class SphereDesc(C.Structure):
 
 
 class MaterialDesc(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("a", C.c_float * 3), ("b", C.c_float * 3), ("c", C.c_float), ("flags", C.c_uint32)]
+    _fields_ = [("kind", C.c_uint32), ("a", C.c_float * 3), ("b", C.c_float * 3), ("c", C.c_float), ("flags", C.c_uint32), ("a_texture", C.c_uint32)]
+
+
+class TextureDesc(C.Structure):
+    """textures/image_texture.rs:49-56: row-major RGB f32, row 0 = top row of the file."""
+
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb", C.POINTER(C.c_float))]
 
 
 class LightDesc(C.Structure):
@@ -66,6 +72,8 @@ class SceneDesc(C.Structure):
         ("split_method", C.c_uint32),
         ("max_shapes_in_node", C.c_uint32),
         ("shape_order", u32p),
+        ("n_textures", C.c_uint32),
+        ("textures", C.POINTER(TextureDesc)),
     ]
 
 

@@ -75,7 +75,7 @@ struct yk_scene {
     uint32_t n_triangles = 0, n_spheres = 0, n_lights = 0;
     yk_scene_info info;
     // device
-    DevBuf nodes, tris, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights, spheres;
+    DevBuf nodes, tris, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights, spheres, texels, tex_info;
     DevScene dev;
     bool on_device = false;
 };
@@ -269,10 +269,12 @@ static Material make_material(const yk_material_desc& m) {
         r.a[k] = m.a[k];
         r.b[k] = m.b[k];
     }
-    const bool remap = (m.flags & 1u) != 0;
+    const bool remap = (m.flags & YK_MAT_FLAG_REMAP) != 0;
+    const bool textured = m.kind == YK_MAT_MATTE && (m.flags & YK_MAT_FLAG_TEXTURED_A) != 0;
+    r.tex = textured ? m.a_texture + 1u : 0u;
     switch (m.kind) {
-        case YK_MAT_MATTE: {  // matte.rs:27-39
-            if (m.a[0] == 0.0f && m.a[1] == 0.0f && m.a[2] == 0.0f) {
+        case YK_MAT_MATTE: {  // matte.rs:27-39 (a textured Kd is tested for black per hit)
+            if (!textured && m.a[0] == 0.0f && m.a[1] == 0.0f && m.a[2] == 0.0f) {
                 r.kind = MK_BLACK;
             } else if (m.c == 0.0f) {
                 r.kind = MK_LAMBERT;
@@ -340,6 +342,13 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
     }
     for (uint32_t k = 0; k < d->n_spheres; ++k)
         if (d->spheres[k].material < 0 || (uint32_t)d->spheres[k].material >= d->n_materials) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "sphere material out of range");
+    for (uint32_t m = 0; m < d->n_materials; ++m)
+        if ((d->materials[m].flags & YK_MAT_FLAG_TEXTURED_A) && d->materials[m].kind == YK_MAT_MATTE && d->materials[m].a_texture >= d->n_textures)
+            return fail(ctx, YK_ERR_INVALID_ARGUMENT, "material texture index out of range");
+    for (uint32_t t = 0; t < d->n_textures; ++t)
+        if (!d->textures || !d->textures[t].rgb || d->textures[t].width == 0 || d->textures[t].height == 0 || d->textures[t].width >= (1u << 24) ||
+            d->textures[t].height >= (1u << 24))
+            return fail(ctx, YK_ERR_INVALID_ARGUMENT, "bad texture");
     if (d->n_triangles && (!d->tri_material || d->n_materials == 0 || d->n_meshes == 0))
         return fail(ctx, YK_ERR_INVALID_ARGUMENT, "triangles need materials and meshes");
     for (uint32_t m = 0; m < d->n_meshes; ++m) {
@@ -516,6 +525,20 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         UP(materials, mats.data(), mats.size());
         UP(lights, lights.data(), lights.size());
         UP(spheres, spheres.data(), spheres.size());
+        std::vector<uint4> tex_info;
+        std::vector<float4> texels;
+        for (uint32_t t = 0; t < d->n_textures; ++t) {
+            const yk_texture_desc& td = d->textures[t];
+            tex_info.push_back(make_uint4((unsigned)texels.size(), td.width, td.height, 0u));
+            const size_t n = (size_t)td.width * td.height;
+            if (texels.size() + n > 0xffffffffull) {
+                yk_scene_destroy(s);
+                return fail(ctx, YK_ERR_UNSUPPORTED, "more than 2^32 texels");
+            }
+            for (size_t k = 0; k < n; ++k) texels.push_back(make_float4(td.rgb[3 * k], td.rgb[3 * k + 1], td.rgb[3 * k + 2], 0.0f));
+        }
+        UP(texels, texels.data(), texels.size());
+        UP(tex_info, tex_info.data(), tex_info.size());
 #undef UP
         DevScene& ds = s->dev;
         ds.nodes = s->nodes.as<DevNode>();
@@ -539,10 +562,12 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         ds.materials = s->materials.as<Material>();
         ds.lights = s->lights.as<DevLight>();
         ds.n_lights = d->n_lights;
+        ds.texels = d->n_textures ? s->texels.as<float4>() : nullptr;
+        ds.tex_info = d->n_textures ? s->tex_info.as<uint4>() : nullptr;
         s->on_device = true;
         s->info.upload_seconds = now_seconds() - u0;
         DevBuf* all[] = {&s->nodes, &s->tris, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
-                         &s->mesh_flags, &s->materials, &s->lights, &s->spheres};
+                         &s->mesh_flags, &s->materials, &s->lights, &s->spheres, &s->texels, &s->tex_info};
         for (DevBuf* b : all) s->info.device_bytes += b->bytes;
     }
     *out = s;
@@ -553,7 +578,7 @@ void yk_scene_destroy(yk_scene* s) {
     if (!s) return;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
     DevBuf* all[] = {&s->nodes, &s->tris, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
-                     &s->mesh_flags, &s->materials, &s->lights, &s->spheres};
+                     &s->mesh_flags, &s->materials, &s->lights, &s->spheres, &s->texels, &s->tex_info};
     for (DevBuf* b : all) b->release();
     delete s;
 }

@@ -19,7 +19,7 @@ namespace yk {
 // BxdfType bits, bsdfs/mod.rs:24-34
 enum : int { BX_NONE = 0, BX_REFLECTION = 1, BX_TRANSMISSION = 2, BX_DIFFUSE = 4, BX_GLOSSY = 8, BX_SPECULAR = 16 };
 
-// Device material record (40 B): yk_material_desc with the per-hit constants the
+// Device material record (44 B): yk_material_desc with the per-hit constants the
 // reference recomputes on every hit folded in where that is bit-identical.
 struct Material {
     unsigned kind;   // 0 matte(lambert) 1 glass 2 metal 3 glossy 4 matte(oren-nayar) 5 black (no lobes)
@@ -27,6 +27,7 @@ struct Material {
     float b[3];      //    | T | k   |
     float c;         // oren-nayar A | glass eta | alpha (after remap / square / clamp)
     float d;         // oren-nayar B
+    unsigned tex;    // matte: 1 + index of the ImageTexture that supplies Kd, 0 = constant
 };
 enum : unsigned { MK_LAMBERT = 0, MK_GLASS = 1, MK_METAL = 2, MK_GLOSSY = 3, MK_OREN_NAYAR = 4, MK_BLACK = 5 };
 

@@ -93,6 +93,9 @@ struct DevScene {
     const DevLight* lights;
     uint32_t n_lights;
     float background[3];
+    // image textures: texels of all textures back to back (rgb, 0), per-texture (first texel, width, height, 0)
+    const float4* texels;
+    const uint4* tex_info;
 };
 
 struct DevCamera {

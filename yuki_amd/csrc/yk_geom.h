@@ -94,6 +94,7 @@ struct Surface {
     V3 wo;      // si.wo (== -ray.d for triangles; re-normalised through the transform for spheres)
     int material;
     int area_light;
+    float u, v;  // si.uv — read only by image textures
 };
 
 YK_HD V3 ld3(const float* a, uint32_t i) { return V3{a[3 * i], a[3 * i + 1], a[3 * i + 2]}; }
@@ -129,13 +130,19 @@ YK_HD bool sphere_hit_t(const DevSphere& sp, V3 o, V3 d, float t_max, float& t_o
 
 // Rest of Sphere::intersect (sphere.rs:79-116) + Transform * SurfaceInteraction
 // (interaction.rs:141-164): the world-space surface the integrator sees.
-YK_HD Surface make_surface_sphere(const DevSphere& sp, V3 ro, V3 rd, float t, V3 world_d) {
+YK_HD Surface make_surface_sphere(const DevSphere& sp, V3 ro, V3 rd, float t, V3 world_d, bool want_uv) {
     V3 p = ro + rd * t;  // Ray::point
     p = p * (sp.radius / length(p - V3{0.0f, 0.0f, 0.0f}));
     if (p.x == 0.0f && p.y == 0.0f) p.x = 1e-5f * sp.radius;
-    // (phi = atan2(p.y, p.x) only feeds the uv the integrator never reads)
     const float phi_max = 2.0f * YK_PI, theta_min = YK_PI, theta_max = 0.0f;
     float theta = det_acosf(rclamp(p.z / sp.radius, -1.0f, 1.0f));
+    float su = 0.0f, sv = 0.0f;
+    if (want_uv) {  // sphere.rs:95-103; only image textures read the uv
+        float phi = det_atan2f(p.y, p.x);
+        if (phi < 0.0f) phi += 2.0f * YK_PI;
+        su = phi / phi_max;
+        sv = (theta - theta_min) / (theta_max - theta_min);
+    }
     float z_radius = sqrtf(p.x * p.x + p.y * p.y);
     float inv_z_radius = 1.0f / z_radius;
     float cos_phi = p.x * inv_z_radius;
@@ -159,6 +166,8 @@ YK_HD Surface make_surface_sphere(const DevSphere& sp, V3 ro, V3 rd, float t, V3
     s.ns = faceforward_n(sn, s.n);
     s.material = sp.material;
     s.area_light = -1;
+    s.u = su;
+    s.v = sv;
     return s;
 }
 
@@ -188,6 +197,8 @@ YK_HD Surface make_surface(const DevScene& sc, uint32_t tri, const TriHit& h) {
     (void)dpdv;
     Surface s;
     s.p = p0 * h.b0 + p1 * h.b1 + p2 * h.b2;
+    s.u = u0x * h.b0 + u1x * h.b1 + u2x * h.b2;  // uv_hit, triangle.rs:176
+    s.v = u0y * h.b0 + u1y * h.b1 + u2y * h.b2;
     V3 n = normalize(cross(dp02, dp12));
     if (mflags & YK_MESH_SWAPS) n = -n;
     s.n = n;
@@ -227,7 +238,7 @@ YK_HD Surface hit_surface(const DevScene& sc, uint32_t shape, V3 o, V3 d) {
         V3 ro, rd;
         float t = 0.0f;
         sphere_hit_t(sp, o, d, __builtin_inff(), t, ro, rd);
-        return make_surface_sphere(sp, ro, rd, t, d);
+        return make_surface_sphere(sp, ro, rd, t, d, sc.texels != nullptr);
     }
     uint32_t i0 = sc.indices[3 * shape], i1 = sc.indices[3 * shape + 1], i2 = sc.indices[3 * shape + 2];
     RayTri rt = ray_tri_setup(d);
@@ -236,6 +247,26 @@ YK_HD Surface hit_surface(const DevScene& sc, uint32_t shape, V3 o, V3 d) {
     Surface s = make_surface(sc, shape, th);
     s.wo = -d;
     return s;
+}
+
+// ImageTexture::evaluate, textures/image_texture.rs:81-111: repeat, flip v, point sample.
+// `as usize` saturates (NaN and negatives -> 0); the index cannot leave the image.
+YK_HD RGB texture_eval(const DevScene& sc, unsigned tex, float u, float v) {
+    const uint4 info = sc.tex_info[tex];
+    float sx = u - truncf(u);  // f32::fract
+    if (sx < 0.0f) sx = 1.0f + sx;
+    float sy = v - truncf(v);
+    if (sy < 0.0f) sy = 1.0f + sy;
+    sy = 1.0f - sy;
+    float fx = sx * (float)info.y - 0.5f;
+    float fy = sy * (float)info.z - 0.5f;
+    unsigned ix = fx > 0.0f ? (unsigned)fminf(fx, 4.0e9f) : 0u;
+    unsigned iy = fy > 0.0f ? (unsigned)fminf(fy, 4.0e9f) : 0u;
+    size_t idx = (size_t)iy * info.y + ix;
+    const size_t last = (size_t)info.y * info.z - 1;
+    if (idx > last) idx = last;  // unreachable for finite uv (the reference would panic)
+    float4 t = sc.texels[(size_t)info.x + idx];
+    return RGB{t.x, t.y, t.z};
 }
 
 // Interaction::spawn_ray, interaction.rs:27-40

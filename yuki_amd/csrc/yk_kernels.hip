@@ -213,6 +213,13 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderParams prm, 
             if (hit) {
                 sf = hit_surface(sc, (uint32_t)tri, o, d);
                 mat = sc.materials[sf.material];
+                if (mat.tex) {  // matte.rs:29-30: reflectance = kd.evaluate(si); no lobe when black
+                    RGB kd = texture_eval(sc, mat.tex - 1u, sf.u, sf.v);
+                    mat.a[0] = kd.r;
+                    mat.a[1] = kd.g;
+                    mat.a[2] = kd.b;
+                    if (is_black(kd)) mat.kind = MK_BLACK;
+                }
                 fr = make_frame(sf.n, sf.ns, sf.dpdus);
                 wo = -d;
             }

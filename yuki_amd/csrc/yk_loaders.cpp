@@ -41,12 +41,16 @@ struct yk_loaded_scene {
     std::vector<yk_sphere_desc> spheres;
     std::vector<yk_material_desc> materials;
     std::vector<yk_light_desc> lights;
+    std::vector<std::vector<float>> texture_data;
+    std::vector<yk_texture_desc> textures;
     float background[3] = {0, 0, 0};
     yk_camera_params camera;
     uint16_t tile_dim = 16;
     uint32_t split_method = YK_SPLIT_SAH, max_shapes_in_node = 1;
     bool any_normals = false, any_uvs = false;
 };
+
+yk_status yk_image_decode_file(const std::string& path, uint32_t& w, uint32_t& h, std::vector<float>& rgb, std::string& err);  // yk_image.cpp
 
 static thread_local std::string g_loader_error;
 static yk_status lfail(yk_status st, const std::string& msg) {
@@ -564,7 +568,7 @@ Xf xf_rotation(float theta, V3 axis) {
 }
 
 // get_material, pbrt/mod.rs:860-936
-yk_status get_material(const std::string& type, const ParamSet& p, const std::map<std::string, bool>& textures, yk_material_desc& out) {
+yk_status get_material(const std::string& type, const ParamSet& p, const std::map<std::string, int>& textures, yk_material_desc& out) {
     const float ones[3] = {1, 1, 1}, half[3] = {0.5f, 0.5f, 0.5f};
     float a[3], b[3];
     if (type == "glass") {
@@ -576,14 +580,21 @@ yk_status get_material(const std::string& type, const ParamSet& p, const std::ma
         out = make_mat(YK_MAT_GLOSSY, a, nullptr, p.f32("roughness", 0.5f), false);
     } else if (type == "matte") {
         std::string kd_tex = p.str("Kd", "");
+        int tex = -1;
         if (!kd_tex.empty()) {
-            if (textures.count(kd_tex)) return lfail(YK_ERR_UNSUPPORTED, "Texture '" + kd_tex + "': image textures are not supported yet");
-            return lfail(YK_ERR_INVALID_ARGUMENT, "Texture '" + kd_tex + "' not found");
+            auto it = textures.find(kd_tex);
+            if (it == textures.end()) return lfail(YK_ERR_INVALID_ARGUMENT, "Texture '" + kd_tex + "' not found");
+            tex = it->second;
+        } else {
+            p.vec3(p.spectra, "Kd", half, a);
         }
-        p.vec3(p.spectra, "Kd", half, a);
         const float rpd = YK_PI / 180.0f;  // f32::to_radians, applied twice (quirk 12)
         float sigma = p.f32("sigma", 0.0f) * rpd;
-        out = make_mat(YK_MAT_MATTE, a, nullptr, sigma * rpd, false);
+        out = make_mat(YK_MAT_MATTE, tex < 0 ? a : nullptr, nullptr, sigma * rpd, false);
+        if (tex >= 0) {
+            out.flags |= YK_MAT_FLAG_TEXTURED_A;
+            out.a_texture = (uint32_t)tex;
+        }
     } else if (type == "metal") {
         std::vector<float> l(COPPER_WAVELENGTHS, COPPER_WAVELENGTHS + 56), n(COPPER_N, COPPER_N + 56), k(COPPER_K, COPPER_K + 56);
         float eta_d[3], k_d[3];
@@ -616,7 +627,7 @@ struct PbrtState {
     std::vector<int> gs_stack;      // GraphicsState = the current material
     std::vector<bool> atb_stack;    // active-transform bits: START set?
     std::map<std::string, int> named;
-    std::map<std::string, bool> textures;  // known imagemap names
+    std::map<std::string, int> textures;   // imagemap name -> index into yk_loaded_scene::textures
     int cur_material = 0;
     bool start_active = true;
     Tok fetched;                    // the reference's `fetched_token` lives across file scopes
@@ -922,9 +933,21 @@ static yk_status load_pbrt_file(const std::string& path, yk_loaded_scene& s, Pbr
             } else if (d == "Texture") {
                 std::string name = str(), ttype = str(), cls = str();
                 ParamSet ps = param_set();
-                if (ttype == "spectrum" && cls == "imagemap") {
-                    if (ps.str("filename", "").empty()) throw fail(YK_ERR_INVALID_ARGUMENT, "missing file for texture '" + name + "'");
-                    S.textures[name] = true;  // image textures: §8(f) rank 2, pixels not loaded yet
+                if (ttype == "spectrum" && cls == "imagemap") {  // pbrt/mod.rs:719-735
+                    std::string fn = ps.str("filename", "");
+                    if (fn.empty()) throw fail(YK_ERR_INVALID_ARGUMENT, "missing file for texture '" + name + "'");
+                    uint32_t w = 0, h = 0;
+                    std::vector<float> rgb;
+                    std::string err;
+                    yk_status st = yk_image_decode_file(parent + "/" + fn, w, h, rgb, err);
+                    if (st != YK_OK) return lfail(st, err);
+                    s.texture_data.push_back(std::move(rgb));
+                    yk_texture_desc td;
+                    td.width = w;
+                    td.height = h;
+                    td.rgb = nullptr;  // fixed up in yk_loaded_scene_get (the vectors may still move)
+                    s.textures.push_back(td);
+                    S.textures[name] = (int)s.textures.size() - 1;  // HashMap::insert replaces
                 }
             } else if (d == "TransformBegin") {
                 S.xf_stack.push_back(S.current);
@@ -958,6 +981,7 @@ static void default_camera(yk_loaded_scene& s) {
 extern "C" {
 
 const char* yk_loader_last_error(void) { return g_loader_error.c_str(); }
+void yk_loader_set_error(const char* msg) { g_loader_error = msg ? msg : ""; }
 
 yk_status yk_load_ply(const char* path, uint32_t split_method, uint32_t max_shapes_in_node, yk_loaded_scene** out) {
     if (!path || !out) return lfail(YK_ERR_INVALID_ARGUMENT, "null argument");
@@ -1038,6 +1062,10 @@ yk_status yk_loaded_scene_get(const yk_loaded_scene* s, yk_scene_desc* d, yk_cam
     d->lights = s->lights.data();
     for (int k = 0; k < 3; ++k) d->background[k] = s->background[k];
     d->shape_order = s->shape_order_flat.empty() ? nullptr : s->shape_order_flat.data();
+    yk_loaded_scene* ms = const_cast<yk_loaded_scene*>(s);
+    for (size_t t = 0; t < ms->textures.size(); ++t) ms->textures[t].rgb = ms->texture_data[t].data();
+    d->n_textures = (uint32_t)s->textures.size();
+    d->textures = s->textures.empty() ? nullptr : s->textures.data();
     d->split_method = s->split_method;
     d->max_shapes_in_node = s->max_shapes_in_node;
     if (camera) *camera = s->camera;

@@ -37,6 +37,13 @@ def _np(ptr, shape, dtype):
     return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype).reshape(shape).copy()
 
 
+def _material(m):
+    out = dict(kind=int(m.kind), a=tuple(m.a), b=tuple(m.b), c=float(m.c), remap=bool(m.flags & 1))
+    if m.flags & 2:
+        out["tex"] = int(m.a_texture)
+    return out
+
+
 def _unpack(handle, name, settings):
     L = lib()
     d = abi.SceneDesc()
@@ -54,10 +61,8 @@ def _unpack(handle, name, settings):
         tri_material=_np(d.tri_material, (nt,), np.int32) if nt else np.zeros(0, np.int32),
         tri_area_light=_np(d.tri_area_light, (nt,), np.int32) if nt else np.zeros(0, np.int32),
         meshes=[(bool(d.meshes[k].has_normals), bool(d.meshes[k].has_uvs), bool(d.meshes[k].swaps_handedness)) for k in range(d.n_meshes)],
-        materials=[
-            dict(kind=int(d.materials[k].kind), a=tuple(d.materials[k].a), b=tuple(d.materials[k].b), c=float(d.materials[k].c), remap=bool(d.materials[k].flags & 1))
-            for k in range(d.n_materials)
-        ],
+        materials=[_material(d.materials[k]) for k in range(d.n_materials)],
+        textures=[_np(d.textures[k].rgb, (d.textures[k].height, d.textures[k].width, 3), np.float32) for k in range(d.n_textures)],
         lights=[],
         normals=_np(d.normals, (nv, 3), np.float32),
         uvs=_np(d.uvs, (nv, 2), np.float32),
@@ -101,6 +106,19 @@ def _load(fn_name, settings):
         return _unpack(h, os.path.basename(settings.path), settings)
     finally:
         L.yk_loaded_scene_destroy(h)
+
+
+def load_image_texture(path):
+    """ImageTexture::new(path) (textures/image_texture.rs:66-70): (h, w, 3) float32, row 0 = top."""
+    L = lib()
+    t = abi.TextureDesc()
+    st = L.yk_image_texture_load(os.fspath(path).encode(), C.byref(t))
+    if st != 0:
+        raise YukiError(st, L.yk_loader_last_error().decode(errors="replace"))
+    try:
+        return _np(t.rgb, (t.height, t.width, 3), np.float32)
+    finally:
+        L.yk_image_texture_free(C.byref(t))
 
 
 def load_ply(settings):

@@ -91,6 +91,7 @@ class SceneData:
     shape_order: np.ndarray = None  # Scene.shapes order (ids: triangles, then spheres); None = natural
     film_res: tuple = None  # FilmSettings.res when the scene came from a loader
     light_structs: list = None  # ready abi.LightDesc values (loaders); overrides `lights`
+    textures: list = field(default_factory=list)  # [(h, w, 3) f32 arrays]; a material's `tex` key indexes it
 
     @property
     def n_triangles(self):
@@ -162,7 +163,8 @@ class SceneData:
             mats[k].a = abi.f3(m.get("a", (0, 0, 0)))
             mats[k].b = abi.f3(m.get("b", (0, 0, 0)))
             mats[k].c = float(m.get("c", 0.0))
-            mats[k].flags = 1 if m.get("remap", False) else 0
+            mats[k].flags = (1 if m.get("remap", False) else 0) | (2 if m.get("tex") is not None else 0)
+            mats[k].a_texture = int(m["tex"]) if m.get("tex") is not None else 0
         keep["materials"] = mats
         d.n_materials = len(self.materials)
         d.materials = C.cast(mats, C.POINTER(abi.MaterialDesc))
@@ -173,6 +175,14 @@ class SceneData:
         d.background = abi.f3(self.background)
         d.split_method = self.split_method
         d.max_shapes_in_node = self.max_shapes_in_node
+        texs = (abi.TextureDesc * max(1, len(self.textures)))()
+        keep["texture_arrays"] = [np.ascontiguousarray(t, dtype=F) for t in self.textures]
+        for k, t in enumerate(keep["texture_arrays"]):
+            texs[k].height, texs[k].width = t.shape[0], t.shape[1]
+            texs[k].rgb = abi.ptr(t, abi.f32p)
+        keep["textures"] = texs
+        d.n_textures = len(self.textures)
+        d.textures = C.cast(texs, C.POINTER(abi.TextureDesc))
         keep["shape_order"] = None if self.shape_order is None else np.ascontiguousarray(self.shape_order, dtype=np.uint32)
         d.shape_order = abi.ptr(keep["shape_order"], abi.u32p)
         return d, keep
