@@ -254,6 +254,31 @@ yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const y
                                  const yk_sampler_desc* sampler, const yk_integrator_desc* integrator, const yk_tile* tiles,
                                  size_t n_tiles, void* d_out_rgb, void* stream, yk_render_stats* stats, yk_cancel_fn cancel,
                                  void* user);
+/* Integrator::render(accumulating = true) (integrators/mod.rs:146-161; the tile queue of
+ * render_manager.rs:135-143): ONE sample per pixel whose global sample index is the tile's
+ * FilmTile.sample (tile_samples[t], u16 like film.rs:52); the raw radiance is stored (divided
+ * by 1).  Fold the result into the film with yk_film_accumulate_tiles[_device]; the displayed
+ * image is film / samples (tonemap.rs:240-241). */
+yk_status yk_render_tiles_accumulating(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                       const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
+                                       float* out_rgb, yk_render_stats* stats, yk_cancel_fn cancel, void* user);
+yk_status yk_render_tiles_accumulating_device(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                              const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples,
+                                              size_t n_tiles, void* d_out_rgb, void* stream, yk_render_stats* stats, yk_cancel_fn cancel,
+                                              void* user);
+/* Film::update_tile with `samples` present (film.rs:260-272): film += tile pixels and
+ * tile_sample_counts[t] += 1 (position t in `tiles` plays FilmTile.index; may be NULL). */
+yk_status yk_film_accumulate_tiles(const yk_tile* tiles, size_t n_tiles, const float* tile_rgb, uint16_t res_x, uint16_t res_y, float* film_rgb,
+                                   uint32_t* tile_sample_counts);
+yk_status yk_film_accumulate_tiles_device(yk_context* ctx, const yk_tile* tiles, size_t n_tiles, const void* d_tile_rgb, uint16_t res_x,
+                                          uint16_t res_y, void* d_film_rgb, void* stream);
+/* Film output (app/util.rs:90-111 write_exr -> exr::prelude::write_rgb_file): an OpenEXR 2
+ * scan-line file with three FLOAT channels B, G, R, uncompressed, increasing Y — readable by
+ * the tools the reference targets (readme.md:46-47); and a little-endian PFM ("PF") writer.
+ * pixels: row-major RGB, row 0 = top. */
+yk_status yk_write_exr(const char* path, uint32_t width, uint32_t height, const float* rgb);
+yk_status yk_write_pfm(const char* path, uint32_t width, uint32_t height, const float* rgb);
+
 /* Exactly the trait method: one tile, returns the ray count through *out_rays. */
 yk_status yk_render_tile(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
                          const yk_integrator_desc* integrator, const yk_tile* tile, float* tile_pixels, uint64_t* out_rays);

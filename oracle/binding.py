@@ -49,6 +49,8 @@ def lib():
     L.orc_make_point_light.restype = None
     L.orc_render_tiles.argtypes = [vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), vp, C.c_size_t, vp, C.POINTER(C.c_uint64), C.POINTER(abi.TraceStats), C.c_int, vp]
     L.orc_render_tiles.restype = C.c_int
+    L.orc_render_tiles_accumulating.argtypes = [vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), vp, vp, C.c_size_t, vp, C.POINTER(C.c_uint64), C.c_int]
+    L.orc_render_tiles_accumulating.restype = C.c_int
     L.orc_camera_rays.argtypes = [C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.Tile), C.c_uint32, vp, vp]
     L.orc_camera_rays.restype = None
     L.orc_intersect.argtypes = [vp, C.c_size_t] + [vp] * 11
@@ -179,6 +181,18 @@ class OracleScene:
         if per_sample:
             res.append(ps)
         return tuple(res)
+
+    def render_tiles_accumulating(self, camera, sampler, integrator, tiles, tile_samples, n_threads=1):
+        """Integrator::render(accumulating=true): one sample (index tile_samples[t]) per pixel."""
+        tiles = np.ascontiguousarray(tiles, dtype=abi.TILE_DTYPE)
+        ts = np.ascontiguousarray(tile_samples, dtype=np.uint16)
+        assert len(ts) == len(tiles)
+        npx = int(((tiles["x1"].astype(np.int64) - tiles["x0"]) * (tiles["y1"].astype(np.int64) - tiles["y0"])).sum())
+        out = np.zeros((npx, 3), dtype=np.float32)
+        rays = C.c_uint64(0)
+        rc = lib().orc_render_tiles_accumulating(self.h, C.byref(camera), C.byref(sampler), C.byref(integrator), _p(tiles), _p(ts), len(tiles), _p(out), C.byref(rays), n_threads)
+        assert rc == 0
+        return out, rays.value
 
     def intersect(self, o, d, t_max=None):
         o = np.ascontiguousarray(o, dtype=np.float32)

@@ -270,9 +270,31 @@ static IntegratorParams integ_from(const orc_integrator_desc* d) {
     return p;
 }
 
+}  // extern "C"
+
+static int render_tiles_common(const orc_scene* s, const orc_camera* cam, const orc_sampler_desc* smp, const orc_integrator_desc* integ,
+                               const orc_tile* tiles, const uint16_t* tile_samples, size_t n_tiles, float* out_rgb, uint64_t* out_ray_count,
+                               orc_trace_stats* stats, int n_threads, float* per_sample);
+
+extern "C" {
+
 int orc_render_tiles(const orc_scene* s, const orc_camera* cam, const orc_sampler_desc* smp, const orc_integrator_desc* integ,
                      const orc_tile* tiles, size_t n_tiles, float* out_rgb, uint64_t* out_ray_count, orc_trace_stats* stats,
                      int n_threads, float* per_sample) {
+    return render_tiles_common(s, cam, smp, integ, tiles, nullptr, n_tiles, out_rgb, out_ray_count, stats, n_threads, per_sample);
+}
+
+int orc_render_tiles_accumulating(const orc_scene* s, const orc_camera* cam, const orc_sampler_desc* smp, const orc_integrator_desc* integ,
+                                  const orc_tile* tiles, const uint16_t* tile_samples, size_t n_tiles, float* out_rgb, uint64_t* out_ray_count,
+                                  int n_threads) {
+    return render_tiles_common(s, cam, smp, integ, tiles, tile_samples, n_tiles, out_rgb, out_ray_count, nullptr, n_threads, nullptr);
+}
+
+}  // extern "C"
+
+static int render_tiles_common(const orc_scene* s, const orc_camera* cam, const orc_sampler_desc* smp, const orc_integrator_desc* integ,
+                               const orc_tile* tiles, const uint16_t* tile_samples, size_t n_tiles, float* out_rgb, uint64_t* out_ray_count,
+                               orc_trace_stats* stats, int n_threads, float* per_sample) {
     Camera camera = cam_from(cam);
     Sampler sampler = sampler_from(smp);
     IntegratorParams prm = integ_from(integ);
@@ -301,7 +323,7 @@ int orc_render_tiles(const orc_scene* s, const orc_camera* cam, const orc_sample
             }
             Tile t;
             t.x0 = tiles[ti].x0; t.y0 = tiles[ti].y0; t.x1 = tiles[ti].x1; t.y1 = tiles[ti].y1;
-            rays += render_tile(prm, s->scene, camera, sampler, t, out_rgb + 3 * offsets[ti], -1, stats ? &local : nullptr,
+            rays += render_tile(prm, s->scene, camera, sampler, t, out_rgb + 3 * offsets[ti], tile_samples ? (int)tile_samples[ti] : -1, stats ? &local : nullptr,
                                 per_sample ? per_sample + 3 * offsets[ti] * spp : nullptr);
         }
         total_rays += rays;
@@ -328,6 +350,8 @@ int orc_render_tiles(const orc_scene* s, const orc_camera* cam, const orc_sample
     }
     return 0;
 }
+
+extern "C" {
 
 void orc_camera_rays(const orc_camera* cam, const orc_sampler_desc* smp, const orc_tile* tile, uint32_t sample_index,
                      float* out_o, float* out_d) {

@@ -149,6 +149,12 @@ int orc_render_tiles(const orc_scene* s, const orc_camera* cam, const orc_sample
                      const orc_tile* tiles, size_t n_tiles, float* out_rgb, uint64_t* out_ray_count, orc_trace_stats* stats,
                      int n_threads, float* per_sample /* nullable */);
 
+/* Integrator::render(accumulating = true): one sample per pixel with global index
+ * tile_samples[t] (FilmTile.sample), raw value stored (integrators/mod.rs:146-182) */
+int orc_render_tiles_accumulating(const orc_scene* s, const orc_camera* cam, const orc_sampler_desc* smp, const orc_integrator_desc* integ,
+                                  const orc_tile* tiles, const uint16_t* tile_samples, size_t n_tiles, float* out_rgb, uint64_t* out_ray_count,
+                                  int n_threads);
+
 /* per-stage entry points */
 void orc_camera_rays(const orc_camera* cam, const orc_sampler_desc* smp, const orc_tile* tile, uint32_t sample_index,
                      float* out_o, float* out_d);

@@ -103,6 +103,12 @@ SYMBOLS = {
     "yk_loader_last_error": (C.c_char_p, []),
     "yk_image_texture_load": (C.c_int, [C.c_char_p, C.POINTER(abi.TextureDesc)]),
     "yk_image_texture_free": (None, [C.POINTER(abi.TextureDesc)]),
+    "yk_render_tiles_accumulating": (C.c_int, [vp, vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), vp, vp, C.c_size_t, vp, C.POINTER(RenderStats), vp, vp]),
+    "yk_render_tiles_accumulating_device": (C.c_int, [vp, vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), vp, vp, C.c_size_t, vp, vp, C.POINTER(RenderStats), vp, vp]),
+    "yk_film_accumulate_tiles": (C.c_int, [vp, C.c_size_t, vp, C.c_uint16, C.c_uint16, vp, vp]),
+    "yk_film_accumulate_tiles_device": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_uint16, C.c_uint16, vp, vp]),
+    "yk_write_exr": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, vp]),
+    "yk_write_pfm": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, vp]),
 }
 
 

@@ -69,6 +69,29 @@ def update_tiles(tiles, tile_rgb, res):
     return film
 
 
+def accumulate_tiles(tiles, tile_rgb, film, tile_sample_counts=None):
+    """Film::update_tile with accumulation on (film.rs:260-272): film += tile pixels, in place;
+    tile_sample_counts[t] += 1."""
+    tiles = np.ascontiguousarray(tiles, dtype=abi.TILE_DTYPE)
+    tile_rgb = np.ascontiguousarray(tile_rgb, dtype=np.float32)
+    assert film.dtype == np.float32 and film.flags["C_CONTIGUOUS"]
+    if tile_sample_counts is not None:
+        assert tile_sample_counts.dtype == np.uint32 and len(tile_sample_counts) == len(tiles)
+    check(lib().yk_film_accumulate_tiles(_p(tiles), len(tiles), _p(tile_rgb), film.shape[1], film.shape[0], _p(film), _p(tile_sample_counts)))
+    return film
+
+
+def write_exr(path, film):
+    """app/util.rs:90-111 write_exr: (h, w, 3) float32 -> RGB OpenEXR file."""
+    film = np.ascontiguousarray(film, dtype=np.float32)
+    check(lib().yk_write_exr(str(path).encode(), film.shape[1], film.shape[0], _p(film)))
+
+
+def write_pfm(path, film):
+    film = np.ascontiguousarray(film, dtype=np.float32)
+    check(lib().yk_write_pfm(str(path).encode(), film.shape[1], film.shape[0], _p(film)))
+
+
 # --------------------------------------------------------------------------- camera
 class FoV:
     X, Y = abi.FOV_X, abi.FOV_Y
@@ -267,6 +290,23 @@ class Integrator:
         cb = _ffi.CANCEL_FN(lambda _u: 1 if cancel() else 0) if cancel else None
         check(
             lib().yk_render_tiles(self.ctx.h, scene.h, C.byref(camera.matrices), C.byref(sampler), C.byref(self.desc), _p(tiles), len(tiles), _p(out), C.byref(stats), C.cast(cb, C.c_void_p) if cb else None, None),
+            self.ctx.h,
+        )
+        return out, stats
+
+    def render_tiles_accumulating(self, scene, camera, sampler, tiles, tile_samples, cancel=None):
+        """Integrator::render(accumulating=true) (integrators/mod.rs:146-161) for a list of
+        (tile, FilmTile.sample) pairs: one sample per pixel, raw value.  Returns (rgb, stats)."""
+        tiles = np.ascontiguousarray(tiles, dtype=abi.TILE_DTYPE)
+        ts = np.ascontiguousarray(tile_samples, dtype=np.uint16)
+        if len(ts) != len(tiles):
+            raise ValueError("one sample index per tile")
+        npx = int(((tiles["x1"].astype(np.int64) - tiles["x0"]) * (tiles["y1"].astype(np.int64) - tiles["y0"])).sum())
+        out = np.zeros((npx, 3), dtype=np.float32)
+        stats = RenderStats()
+        cb = _ffi.CANCEL_FN(lambda _u: 1 if cancel() else 0) if cancel else None
+        check(
+            lib().yk_render_tiles_accumulating(self.ctx.h, scene.h, C.byref(camera.matrices), C.byref(sampler), C.byref(self.desc), _p(tiles), _p(ts), len(tiles), _p(out), C.byref(stats), C.cast(cb, C.c_void_p) if cb else None, None),
             self.ctx.h,
         )
         return out, stats

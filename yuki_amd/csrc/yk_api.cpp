@@ -261,6 +261,26 @@ yk_status yk_film_update_tiles(const yk_tile* tiles, size_t n_tiles, const float
     return YK_OK;
 }
 
+// Film::update_tile with accumulation on (film.rs:260-272): film += tile ; samples[tile] += 1
+yk_status yk_film_accumulate_tiles(const yk_tile* tiles, size_t n_tiles, const float* tile_rgb, uint16_t res_x, uint16_t res_y, float* film_rgb,
+                                   uint32_t* tile_sample_counts) {
+    if (!tiles || !tile_rgb || !film_rgb) return YK_ERR_INVALID_ARGUMENT;
+    size_t off = 0;
+    for (size_t t = 0; t < n_tiles; ++t) {
+        const yk_tile& tl = tiles[t];
+        if (tl.x1 > res_x || tl.y1 > res_y || tl.x0 >= tl.x1 || tl.y0 >= tl.y1) return YK_ERR_INVALID_ARGUMENT;
+        size_t w = (size_t)tl.x1 - tl.x0;
+        for (size_t y = tl.y0; y < tl.y1; ++y) {
+            float* dst = film_rgb + 3 * (y * res_x + tl.x0);
+            const float* src = tile_rgb + 3 * off;
+            for (size_t k = 0; k < 3 * w; ++k) dst[k] += src[k];
+            off += w;
+        }
+        if (tile_sample_counts) tile_sample_counts[t] += 1;
+    }
+    return YK_OK;
+}
+
 // ------------------------------------------------------------------ scene
 static Material make_material(const yk_material_desc& m) {
     Material r;
@@ -719,9 +739,14 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
     }
 }
 
-yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
-                                 const yk_integrator_desc* integrator, const yk_tile* tiles, size_t n_tiles, void* d_out_rgb, void* stream,
-                                 yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
+}  // extern "C"
+
+// Integrator::render for a list of tiles.  tile_samples == nullptr: the plain film (all
+// samples of a pixel, mean stored).  Otherwise the accumulating film (integrators/mod.rs:
+// 146-161): one sample per pixel with global index tile_samples[t], raw value stored.
+static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                   const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
+                                   void* d_out_rgb, void* stream, yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     if (!scene || !camera || !tiles || n_tiles == 0 || !d_out_rgb) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     if (!scene->on_device || scene->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context");
@@ -742,7 +767,8 @@ yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const y
         if (total_px > 0xFFFFFFFFull) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many pixels in one call");
         off[t + 1] = (uint32_t)total_px;
     }
-    const uint32_t spp = prm.sampler.spp;
+    const bool accumulating = tile_samples != nullptr;
+    const uint32_t spp = accumulating ? 1u : prm.sampler.spp;  // samples rendered per pixel by this call
     // chunk so that sample ids fit u32 and the sample buffer stays under the cap
     uint64_t max_px_chunk = std::min<uint64_t>(0xFFFFFFF0ull / spp, (uint64_t)ctx->sample_buf_cap / (16ull * spp));
     if (max_px_chunk == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "sample_buf_cap too small for one pixel");
@@ -810,7 +836,16 @@ yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const y
         HIP_TRY(ctx, ctx->sample_buf.ensure((size_t)npx * spp * 16));
         uint32_t* pixel_xy = ctx->pixel_xy.as<uint32_t>();
         float4* sample_buf = ctx->sample_buf.as<float4>();
-        launch_pixel_table(st, ctx->tiles.as<yk_tile>(), ctx->tile_off.as<uint32_t>(), (uint32_t)(t_end - t_begin), npx, pixel_xy);
+        uint32_t* pixel_sample = nullptr;
+        const uint16_t* d_tile_sample = nullptr;
+        if (accumulating) {
+            HIP_TRY(ctx, ctx->scratch[4].ensure((t_end - t_begin) * 2));
+            HIP_TRY(ctx, ctx->scratch[5].ensure((size_t)npx * 4));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[4].p, tile_samples + t_begin, (t_end - t_begin) * 2, hipMemcpyHostToDevice, st));
+            d_tile_sample = ctx->scratch[4].as<uint16_t>();
+            pixel_sample = ctx->scratch[5].as<uint32_t>();
+        }
+        launch_pixel_table(st, ctx->tiles.as<yk_tile>(), ctx->tile_off.as<uint32_t>(), (uint32_t)(t_end - t_begin), npx, pixel_xy, d_tile_sample, pixel_sample);
         // the second stream starts after the pixel table exists
         if (n_ws == 2) {
             HIP_TRY(ctx, hipEventRecord(ctx->ws[0].done, st));
@@ -832,10 +867,10 @@ yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const y
             unsigned* ctrl = ws.ctrl.as<unsigned>();
             const uint32_t n = (uint32_t)std::min<uint64_t>(batch, work - w0);
             HIP_TRY(ctx, hipMemsetAsync(ctrl, 0, YK_CTRL_WORDS * 4, bs));
-            launch_raygen(bs, cam, prm, pixel_xy, w0, n, path_buffers(ws, 0), sample_buf, ctrl);
+            launch_raygen(bs, cam, prm, pixel_xy, pixel_sample, w0, n, path_buffers(ws, 0), sample_buf, ctrl);
             ++n_batches;
             if (is_path) {
-                run_bounces(ctx, ws, bs, scene, prm, pixel_xy, nullptr, sample_buf, kt, counters);
+                run_bounces(ctx, ws, bs, scene, prm, pixel_xy, pixel_sample, sample_buf, kt, counters);
                 n_trace += prm.max_depth;
             } else {
                 PathBuffers pc = path_buffers(ws, 0);
@@ -889,9 +924,45 @@ yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const y
     return YK_OK;
 }
 
+static yk_status render_tiles_host(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                   const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
+                                   float* out_rgb, yk_render_stats* stats, yk_cancel_fn cancel, void* user);
+
+extern "C" {
+
+yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                 const yk_integrator_desc* integrator, const yk_tile* tiles, size_t n_tiles, void* d_out_rgb, void* stream,
+                                 yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
+    return render_tiles_impl(ctx, scene, camera, sampler, integrator, tiles, nullptr, n_tiles, d_out_rgb, stream, stats, cancel, user);
+}
+
+yk_status yk_render_tiles_accumulating_device(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                              const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
+                                              void* d_out_rgb, void* stream, yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!tile_samples) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null tile_samples");
+    return render_tiles_impl(ctx, scene, camera, sampler, integrator, tiles, tile_samples, n_tiles, d_out_rgb, stream, stats, cancel, user);
+}
+
+yk_status yk_render_tiles_accumulating(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                       const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
+                                       float* out_rgb, yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!tile_samples) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null tile_samples");
+    return render_tiles_host(ctx, scene, camera, sampler, integrator, tiles, tile_samples, n_tiles, out_rgb, stats, cancel, user);
+}
+
 yk_status yk_render_tiles(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
                           const yk_integrator_desc* integrator, const yk_tile* tiles, size_t n_tiles, float* out_rgb, yk_render_stats* stats,
                           yk_cancel_fn cancel, void* user) {
+    return render_tiles_host(ctx, scene, camera, sampler, integrator, tiles, nullptr, n_tiles, out_rgb, stats, cancel, user);
+}
+
+}  // extern "C"
+
+static yk_status render_tiles_host(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                   const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
+                                   float* out_rgb, yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     if (!tiles || n_tiles == 0 || !out_rgb) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     uint64_t total_px = 0;
@@ -902,12 +973,14 @@ yk_status yk_render_tiles(yk_context* ctx, const yk_scene* scene, const yk_camer
     (void)hipSetDevice(ctx->device);
     HIP_TRY(ctx, ctx->scratch[0].ensure(total_px * 12));
     yk_render_stats local;
-    yk_status st = yk_render_tiles_device(ctx, scene, camera, sampler, integrator, tiles, n_tiles, ctx->scratch[0].p, nullptr, stats ? stats : &local,
-                                          cancel, user);
+    yk_status st = render_tiles_impl(ctx, scene, camera, sampler, integrator, tiles, tile_samples, n_tiles, ctx->scratch[0].p, nullptr,
+                                     stats ? stats : &local, cancel, user);
     if (st != YK_OK) return st;
     HIP_TRY(ctx, hipMemcpy(out_rgb, ctx->scratch[0].p, total_px * 12, hipMemcpyDeviceToHost));
     return YK_OK;
 }
+
+extern "C" {
 
 yk_status yk_render_tile(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
                          const yk_integrator_desc* integrator, const yk_tile* tile, float* tile_pixels, uint64_t* out_rays) {
@@ -917,8 +990,27 @@ yk_status yk_render_tile(yk_context* ctx, const yk_scene* scene, const yk_camera
     return st;
 }
 
+}  // extern "C"
+
+static yk_status film_tiles_device(yk_context* ctx, const yk_tile* tiles, size_t n_tiles, const void* d_tile_rgb, uint16_t res_x, uint16_t res_y,
+                                   void* d_film_rgb, void* stream, int accumulate);
+
+extern "C" {
+
 yk_status yk_film_update_tiles_device(yk_context* ctx, const yk_tile* tiles, size_t n_tiles, const void* d_tile_rgb, uint16_t res_x, uint16_t res_y,
                                       void* d_film_rgb, void* stream) {
+    return film_tiles_device(ctx, tiles, n_tiles, d_tile_rgb, res_x, res_y, d_film_rgb, stream, 0);
+}
+
+yk_status yk_film_accumulate_tiles_device(yk_context* ctx, const yk_tile* tiles, size_t n_tiles, const void* d_tile_rgb, uint16_t res_x, uint16_t res_y,
+                                          void* d_film_rgb, void* stream) {
+    return film_tiles_device(ctx, tiles, n_tiles, d_tile_rgb, res_x, res_y, d_film_rgb, stream, 1);
+}
+
+}  // extern "C"
+
+static yk_status film_tiles_device(yk_context* ctx, const yk_tile* tiles, size_t n_tiles, const void* d_tile_rgb, uint16_t res_x, uint16_t res_y,
+                                   void* d_film_rgb, void* stream, int accumulate) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     if (!tiles || !d_tile_rgb || !d_film_rgb || n_tiles == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     (void)hipSetDevice(ctx->device);
@@ -940,11 +1032,13 @@ yk_status yk_film_update_tiles_device(yk_context* ctx, const yk_tile* tiles, siz
     HIP_TRY(ctx, hipStreamSynchronize(st));
     launch_pixel_table(st, ctx->scratch[1].as<yk_tile>(), ctx->scratch[2].as<uint32_t>(), (uint32_t)n_tiles, (uint32_t)total, ctx->scratch[3].as<uint32_t>());
     launch_film_scatter(st, ctx->scratch[3].as<uint32_t>(), (uint32_t)total, reinterpret_cast<const float*>(d_tile_rgb), res_x,
-                        reinterpret_cast<float*>(d_film_rgb));
+                        reinterpret_cast<float*>(d_film_rgb), accumulate);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return YK_OK;
 }
+
+extern "C" {
 
 yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* sampler, const yk_integrator_desc* integrator, size_t n,
                 const float* ray_o, const float* ray_d, const uint16_t* pixel_xy, const uint32_t* sample_index, uint32_t dimension, float* out_li,
@@ -1143,7 +1237,7 @@ yk_status yk_camera_rays(yk_context* ctx, const yk_camera* camera, const yk_samp
     std::memcpy(cam.c2w, camera->camera_to_world, 64);
     std::memcpy(cam.r2c, camera->raster_to_camera, 64);
     PathBuffers pb = path_buffers(ctx->ws[0], 0);
-    launch_raygen(st, cam, prm, ctx->pixel_xy.as<uint32_t>(), 0, npx * spp, pb, ctx->sample_buf.as<float4>(), ctx->ws[0].ctrl.as<unsigned>());
+    launch_raygen(st, cam, prm, ctx->pixel_xy.as<uint32_t>(), nullptr, 0, npx * spp, pb, ctx->sample_buf.as<float4>(), ctx->ws[0].ctrl.as<unsigned>());
     launch_unpack_rays(st, (size_t)npx * spp, pb.rayO, pb.rayD, ctx->scratch[4].as<float>(), ctx->scratch[5].as<float>());
     HIP_TRY(ctx, hipGetLastError());
     std::vector<float> o((size_t)npx * spp * 3), d((size_t)npx * spp * 3);

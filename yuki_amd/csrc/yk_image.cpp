@@ -358,6 +358,81 @@ yk_status yk_image_texture_load(const char* path, yk_texture_desc* out) {
     return YK_OK;
 }
 
+// ---- film output ---------------------------------------------------------------------
+// OpenEXR 2 single-part scan-line file, three FLOAT channels, NO_COMPRESSION (one scan line
+// per chunk), INCREASING_Y.  Layout per the OpenEXR file-layout specification.
+yk_status yk_write_exr(const char* path, uint32_t width, uint32_t height, const float* rgb) {
+    if (!path || !rgb || width == 0 || height == 0 || width > (1u << 26) || height > (1u << 26)) return YK_ERR_INVALID_ARGUMENT;
+    std::vector<uint8_t> hd;
+    auto put = [&](const void* p, size_t n) { hd.insert(hd.end(), (const uint8_t*)p, (const uint8_t*)p + n); };
+    auto str = [&](const char* z) { put(z, std::strlen(z) + 1); };
+    auto i32 = [&](int32_t v) { put(&v, 4); };
+    auto f32 = [&](float v) { put(&v, 4); };
+    auto attr = [&](const char* name, const char* type, int32_t size) {
+        str(name);
+        str(type);
+        i32(size);
+    };
+    const uint32_t magic = 20000630u, version = 2u;
+    put(&magic, 4);
+    put(&version, 4);
+    attr("channels", "chlist", 3 * (2 + 16) + 1);
+    for (const char* c : {"B", "G", "R"}) {
+        str(c);
+        i32(2);  // FLOAT
+        const uint8_t lin[4] = {0, 0, 0, 0};
+        put(lin, 4);
+        i32(1);
+        i32(1);
+    }
+    hd.push_back(0);
+    attr("compression", "compression", 1);
+    hd.push_back(0);
+    attr("dataWindow", "box2i", 16);
+    i32(0); i32(0); i32((int32_t)width - 1); i32((int32_t)height - 1);
+    attr("displayWindow", "box2i", 16);
+    i32(0); i32(0); i32((int32_t)width - 1); i32((int32_t)height - 1);
+    attr("lineOrder", "lineOrder", 1);
+    hd.push_back(0);
+    attr("pixelAspectRatio", "float", 4);
+    f32(1.0f);
+    attr("screenWindowCenter", "v2f", 8);
+    f32(0.0f); f32(0.0f);
+    attr("screenWindowWidth", "float", 4);
+    f32(1.0f);
+    hd.push_back(0);
+    std::FILE* f = std::fopen(path, "wb");
+    if (!f) return ifail(YK_ERR_INVALID_ARGUMENT, std::string("Error writing EXR to '") + path + "'");
+    const uint64_t line_bytes = 8ull + 12ull * width;
+    bool ok = std::fwrite(hd.data(), 1, hd.size(), f) == hd.size();
+    uint64_t off = hd.size() + 8ull * height;
+    for (uint32_t y = 0; y < height && ok; ++y, off += line_bytes) ok = std::fwrite(&off, 8, 1, f) == 1;
+    std::vector<float> line(3 * (size_t)width);
+    for (uint32_t y = 0; y < height && ok; ++y) {
+        const float* src = rgb + 3 * (size_t)y * width;
+        for (uint32_t x = 0; x < width; ++x) {
+            line[x] = src[3 * x + 2];              // B
+            line[width + x] = src[3 * x + 1];      // G
+            line[2 * (size_t)width + x] = src[3 * x];  // R
+        }
+        const int32_t yy = (int32_t)y, sz = (int32_t)(12u * width);
+        ok = std::fwrite(&yy, 4, 1, f) == 1 && std::fwrite(&sz, 4, 1, f) == 1 && std::fwrite(line.data(), 4, line.size(), f) == line.size();
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? YK_OK : ifail(YK_ERR_INVALID_ARGUMENT, std::string("Error writing EXR to '") + path + "'");
+}
+
+// Portable Float Map: "PF", little endian (negative scale), rows stored bottom to top
+yk_status yk_write_pfm(const char* path, uint32_t width, uint32_t height, const float* rgb) {
+    if (!path || !rgb || width == 0 || height == 0) return YK_ERR_INVALID_ARGUMENT;
+    std::FILE* f = std::fopen(path, "wb");
+    if (!f) return ifail(YK_ERR_INVALID_ARGUMENT, std::string("Error writing PFM to '") + path + "'");
+    bool ok = std::fprintf(f, "PF\n%u %u\n-1.0\n", width, height) > 0;
+    for (uint32_t y = height; y-- > 0 && ok;) ok = std::fwrite(rgb + 3 * (size_t)y * width, 4, 3 * (size_t)width, f) == 3 * (size_t)width;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? YK_OK : YK_ERR_INVALID_ARGUMENT;
+}
+
 void yk_image_texture_free(yk_texture_desc* tex) {
     if (!tex) return;
     delete[] tex->rgb;

@@ -10,9 +10,10 @@ unsigned trace_block_size();
 unsigned trace_spill_depth();
 unsigned trace_blocks_per_cu();
 
-void launch_pixel_table(hipStream_t s, const yk_tile* tiles, const uint32_t* tile_offset, uint32_t n_tiles, uint32_t n_pixels, uint32_t* pixel_xy);
-void launch_raygen(hipStream_t s, const DevCamera& cam, const RenderParams& prm, const uint32_t* pixel_xy, uint64_t work0, uint32_t n,
-                   PathBuffers out, float4* sample_buf, unsigned* ctrl);
+void launch_pixel_table(hipStream_t s, const yk_tile* tiles, const uint32_t* tile_offset, uint32_t n_tiles, uint32_t n_pixels, uint32_t* pixel_xy,
+                        const uint16_t* tile_sample = nullptr, uint32_t* pixel_sample = nullptr);
+void launch_raygen(hipStream_t s, const DevCamera& cam, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* pixel_sample, uint64_t work0,
+                   uint32_t n, PathBuffers out, float4* sample_buf, unsigned* ctrl);
 void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, const float* d, const uint16_t* pixel, const uint32_t* sample_index,
                         uint32_t dimension, uint32_t n, PathBuffers out, float4* sample_buf, uint32_t* pixel_xy, unsigned* ctrl);
 void launch_trace_closest(hipStream_t s, unsigned grid, const DevScene& sc, const float4* rayO, const float4* rayD, const float* t_max_opt,
@@ -27,7 +28,7 @@ void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const Render
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
                        const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* ctrl, unsigned cur_slot);
 void launch_resolve(hipStream_t s, const float4* sample_buf, uint32_t n_pixels, uint32_t spp, float* out_rgb);
-void launch_film_scatter(hipStream_t s, const uint32_t* pixel_xy, uint32_t n_pixels, const float* tile_rgb, uint32_t res_x, float* film_rgb);
+void launch_film_scatter(hipStream_t s, const uint32_t* pixel_xy, uint32_t n_pixels, const float* tile_rgb, uint32_t res_x, float* film_rgb, int accumulate = 0);
 void launch_debug_shade(hipStream_t s, const DevScene& sc, uint32_t integrator, PathBuffers cur, const int* hit_tri, const uint4* stats, uint32_t n,
                         float4* sample_buf);
 void launch_device_math(hipStream_t s, int fn, size_t n, const float* a, const float* b, float* out);

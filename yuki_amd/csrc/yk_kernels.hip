@@ -27,7 +27,7 @@ namespace yk {
 // chunk-local pixel index -> pixel coordinates, tile-major / row-major in tile
 // (the order Integrator::render visits them, integrators/mod.rs:145)
 __global__ void k_pixel_table(const yk_tile* tiles, const uint32_t* tile_offset, uint32_t n_tiles, uint32_t n_pixels,
-                              uint32_t* pixel_xy) {
+                              uint32_t* pixel_xy, const uint16_t* tile_sample, uint32_t* pixel_sample) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pixels) return;
     uint32_t lo = 0, hi = n_tiles;  // last tile with offset <= i
@@ -43,6 +43,7 @@ __global__ void k_pixel_table(const yk_tile* tiles, const uint32_t* tile_offset,
     uint32_t r = i - tile_offset[lo];
     uint32_t x = t.x0 + r % w, y = t.y0 + r / w;
     pixel_xy[i] = x | (y << 16);
+    if (tile_sample) pixel_sample[i] = tile_sample[lo];  // FilmTile.sample of the pixel's tile (accumulating film)
 }
 
 // ------------------------------------------------------------------ raygen
@@ -55,14 +56,23 @@ __device__ __forceinline__ void camera_ray(const DevCamera& cam, float fx, float
     d = xf_vector(cam.c2w, dir);
 }
 
-__global__ void k_raygen(DevCamera cam, RenderParams prm, const uint32_t* pixel_xy, uint64_t work0, uint32_t n, PathBuffers out,
-                         float4* sample_buf, unsigned* ctrl) {
+// `pixel_sample` != null: the accumulating film (integrators/mod.rs:146-161) — ONE sample per
+// pixel whose global index is the tile's FilmTile.sample; otherwise all spp samples.
+__global__ void k_raygen(DevCamera cam, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* pixel_sample, uint64_t work0, uint32_t n,
+                         PathBuffers out, float4* sample_buf, unsigned* ctrl) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) ctrl[0] = n;
     if (i >= n) return;
     uint64_t w = work0 + i;
     uint32_t spp = prm.sampler.spp;
-    uint32_t pix = (uint32_t)(w / spp), s = (uint32_t)(w % spp);
+    uint32_t pix, s;
+    if (pixel_sample) {
+        pix = (uint32_t)w;
+        s = pixel_sample[pix];
+    } else {
+        pix = (uint32_t)(w / spp);
+        s = (uint32_t)(w % spp);
+    }
     uint32_t xy = pixel_xy[pix];
     uint32_t px = xy & 0xffffu, py = xy >> 16;
     SamplerState st = sampler_start(prm.sampler, px, py, s, 0);
@@ -387,11 +397,17 @@ __global__ void k_resolve(const float4* sample_buf, uint32_t n_pixels, uint32_t 
 }
 
 // Film::update_tile on the device (film.rs:236-278): tile-major -> row-major film
-__global__ void k_film_scatter(const uint32_t* pixel_xy, uint32_t n_pixels, const float* tile_rgb, uint32_t res_x, float* film_rgb) {
+__global__ void k_film_scatter(const uint32_t* pixel_xy, uint32_t n_pixels, const float* tile_rgb, uint32_t res_x, float* film_rgb, int accumulate) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pixels) return;
     uint32_t xy = pixel_xy[p];
     size_t dst = (size_t)(xy >> 16) * res_x + (xy & 0xffffu);
+    if (accumulate) {  // film.rs:260-272: *fc += c
+        film_rgb[3 * dst + 0] += tile_rgb[3 * (size_t)p + 0];
+        film_rgb[3 * dst + 1] += tile_rgb[3 * (size_t)p + 1];
+        film_rgb[3 * dst + 2] += tile_rgb[3 * (size_t)p + 2];
+        return;
+    }
     film_rgb[3 * dst + 0] = tile_rgb[3 * (size_t)p + 0];
     film_rgb[3 * dst + 1] = tile_rgb[3 * (size_t)p + 1];
     film_rgb[3 * dst + 2] = tile_rgb[3 * (size_t)p + 2];
@@ -504,13 +520,15 @@ __global__ void k_unpack_rays(size_t n, const float4* rayO, const float4* rayD, 
 // ------------------------------------------------------------------ launchers
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
-void launch_pixel_table(hipStream_t s, const yk_tile* tiles, const uint32_t* tile_offset, uint32_t n_tiles, uint32_t n_pixels, uint32_t* pixel_xy) {
+void launch_pixel_table(hipStream_t s, const yk_tile* tiles, const uint32_t* tile_offset, uint32_t n_tiles, uint32_t n_pixels, uint32_t* pixel_xy,
+                        const uint16_t* tile_sample, uint32_t* pixel_sample) {
     if (!n_pixels) return;
-    hipLaunchKernelGGL(k_pixel_table, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, tiles, tile_offset, n_tiles, n_pixels, pixel_xy);
+    hipLaunchKernelGGL(k_pixel_table, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, tiles, tile_offset, n_tiles, n_pixels, pixel_xy, tile_sample,
+                       pixel_sample);
 }
-void launch_raygen(hipStream_t s, const DevCamera& cam, const RenderParams& prm, const uint32_t* pixel_xy, uint64_t work0, uint32_t n,
-                   PathBuffers out, float4* sample_buf, unsigned* ctrl) {
-    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 256)), dim3(256), 0, s, cam, prm, pixel_xy, work0, n, out, sample_buf, ctrl);
+void launch_raygen(hipStream_t s, const DevCamera& cam, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* pixel_sample, uint64_t work0,
+                   uint32_t n, PathBuffers out, float4* sample_buf, unsigned* ctrl) {
+    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 256)), dim3(256), 0, s, cam, prm, pixel_xy, pixel_sample, work0, n, out, sample_buf, ctrl);
 }
 void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, const float* d, const uint16_t* pixel, const uint32_t* sample_index,
                         uint32_t dimension, uint32_t n, PathBuffers out, float4* sample_buf, uint32_t* pixel_xy, unsigned* ctrl) {
@@ -531,9 +549,9 @@ void launch_resolve(hipStream_t s, const float4* sample_buf, uint32_t n_pixels, 
     if (!n_pixels) return;
     hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, sample_buf, n_pixels, spp, out_rgb);
 }
-void launch_film_scatter(hipStream_t s, const uint32_t* pixel_xy, uint32_t n_pixels, const float* tile_rgb, uint32_t res_x, float* film_rgb) {
+void launch_film_scatter(hipStream_t s, const uint32_t* pixel_xy, uint32_t n_pixels, const float* tile_rgb, uint32_t res_x, float* film_rgb, int accumulate) {
     if (!n_pixels) return;
-    hipLaunchKernelGGL(k_film_scatter, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, pixel_xy, n_pixels, tile_rgb, res_x, film_rgb);
+    hipLaunchKernelGGL(k_film_scatter, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, pixel_xy, n_pixels, tile_rgb, res_x, film_rgb, accumulate);
 }
 void launch_debug_shade(hipStream_t s, const DevScene& sc, uint32_t integrator, PathBuffers cur, const int* hit_tri, const uint4* stats, uint32_t n,
                         float4* sample_buf) {
