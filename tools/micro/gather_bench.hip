@@ -1,0 +1,77 @@
+// gather_bench: how fast can a wave fetch 64 random 64-byte records (one per lane)?
+//   mode 0: every lane issues 4 x global_load_dwordx4 on its own record (what traversal does)
+//   mode 1: quad-cooperative — in instruction k lane l fetches piece (l%4) of the record of lane
+//           16k + l/4, so the four lanes of a quad hit one 64-byte record
+//   mode 2: as 1, then exchanged through LDS (ds_write_b128 / ds_read_b128) so that every lane
+//           ends up with its own record
+// Table size is a parameter (fits L2 / Infinity Cache / HBM).  Prints records/s.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+__device__ __forceinline__ unsigned rng(unsigned& s) {
+    s = s * 1664525u + 1013904223u;
+    return s >> 8;
+}
+
+template <int MODE> __global__ __launch_bounds__(256, 6) void k(const float4* __restrict__ table, unsigned n_rec, unsigned iters, float* out) {
+    __shared__ float4 stage[MODE == 2 ? 1024 : 1];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned s = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+    float acc = 0.0f;
+    for (unsigned it = 0; it < iters; ++it) {
+        unsigned idx = rng(s) % n_rec;
+        float4 r0, r1, r2, r3;
+        if (MODE == 0) {
+            const float4* p = table + (size_t)idx * 4;
+            r0 = p[0]; r1 = p[1]; r2 = p[2]; r3 = p[3];
+        } else {
+            unsigned i0 = __shfl(idx, (int)(lane >> 2)), i1 = __shfl(idx, (int)(16 + (lane >> 2))), i2 = __shfl(idx, (int)(32 + (lane >> 2))),
+                     i3 = __shfl(idx, (int)(48 + (lane >> 2)));
+            const unsigned piece = lane & 3u;
+            r0 = table[(size_t)i0 * 4 + piece];
+            r1 = table[(size_t)i1 * 4 + piece];
+            r2 = table[(size_t)i2 * 4 + piece];
+            r3 = table[(size_t)i3 * 4 + piece];
+            if (MODE == 2) {
+                float4* st = stage + wave * 256;
+                st[lane] = r0; st[64 + lane] = r1; st[128 + lane] = r2; st[192 + lane] = r3;
+                __builtin_amdgcn_wave_barrier();
+                r0 = st[4 * lane]; r1 = st[4 * lane + 1]; r2 = st[4 * lane + 2]; r3 = st[4 * lane + 3];
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        acc += r0.x + r1.y + r2.z + r3.w;
+        s ^= __float_as_uint(acc) & 1u;  // dependent chain like a traversal step
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+int main(int argc, char** argv) {
+    size_t mb = argc > 1 ? atoi(argv[1]) : 64;
+    unsigned iters = argc > 2 ? atoi(argv[2]) : 2000;
+    unsigned n_rec = (unsigned)(mb * 1024 * 1024 / 64);
+    float4* table;
+    float* out;
+    hipMalloc(&table, (size_t)n_rec * 64);
+    hipMemset(table, 0, (size_t)n_rec * 64);
+    const int grid = 256 * 6;
+    hipMalloc(&out, grid * 256 * 4);
+    for (int mode = 0; mode < 3; ++mode) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEvent_t a, b;
+            hipEventCreate(&a); hipEventCreate(&b);
+            hipEventRecord(a);
+            if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
+            if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
+            if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
+            hipEventRecord(b);
+            hipEventSynchronize(b);
+            float ms;
+            hipEventElapsedTime(&ms, a, b);
+            if (rep) printf("table %zu MB mode %d: %.3f ms  %.2f G records/s  %.2f TB/s\n", mb, mode, ms, (double)grid * 256 * iters / ms * 1e-6, (double)grid * 256 * iters * 64 / ms * 1e-9);
+        }
+    }
+    return 0;
+}

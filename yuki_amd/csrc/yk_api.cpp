@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -735,6 +736,17 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
                          counters + 1);
         kt.end(e, 1, st);
         launch_accumulate(st, sg, prm, pc, ws.pend.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ds.n_lights, sample_buf, ctrl, cur);
+        if (kt.on && std::getenv("YK_DEBUG_BOUNCES")) {  // per-bounce breakdown (synchronises; diagnostics only)
+            unsigned h[4];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h, ctrl, 16, hipMemcpyDeviceToHost);
+            float tt = 0, ts = 0, th = 0;
+            (void)hipEventElapsedTime(&tt, ctx->ev_pool[kt.spans[0].back().first], ctx->ev_pool[kt.spans[0].back().second]);
+            (void)hipEventElapsedTime(&ts, ctx->ev_pool[kt.spans[1].back().first], ctx->ev_pool[kt.spans[1].back().second]);
+            (void)hipEventElapsedTime(&th, ctx->ev_pool[kt.spans[2].back().first], ctx->ev_pool[kt.spans[2].back().second]);
+            std::fprintf(stderr, "bounce %u: rays %u trace %.3f ms (%.0f Mray/s) | shadow rays %u %.3f ms (%.0f Mray/s) | shade %.3f ms | survivors %u\n", b, h[cur],
+                         tt, h[cur] / (tt * 1e3), h[YK_CTRL_SHQ], ts, h[YK_CTRL_SHQ] / (ts * 1e3), th, h[cur ^ 1u]);
+        }
         cur ^= 1u;
     }
 }
