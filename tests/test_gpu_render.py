@@ -181,3 +181,21 @@ def test_error_behaviour(ctx, yk):
     with pytest.raises(yk.YukiError) as e:
         it.render_tiles(sc, cam, yk.SamplerType.Uniform(1), yk.film_tiles(yk.FilmSettings(res=(32, 32))), cancel=lambda: True)
     assert e.value.status == 7
+
+
+@pytest.mark.parametrize("option,value", [("wide_bvh", 1), ("top_nodes", 0), ("top_nodes", 7)])
+def test_traversal_layout_options_do_not_change_the_image(yk, oracle, option, value):
+    """The optional traversal layouts — the 4-wide collapse of the BVH (DevNode4) and the
+    number of top-of-tree nodes kept in LDS — visit the same leaves in the same order, so the
+    render stays bit-identical to the oracle's (scene with triangles and spheres)."""
+    c = yk.Context(0, **{option: value})
+    try:
+        for name, res in (("cornell", (64, 64)), ("city-tiny", (96, 54))):
+            sd = scenes.by_name(name)
+            sampler = yk.SamplerType.Stratified((2, 2), True, SEED)
+            integ = yk.IntegratorType.Path(yk.PathParams(max_depth=6))
+            got, stats, want, rays = _render_both(c, yk, oracle, sd, res, sampler, integ)
+            assert stats.rays == rays
+            assert np.array_equal(_bits(got), _bits(want))
+    finally:
+        c.close()

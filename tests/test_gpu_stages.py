@@ -127,6 +127,32 @@ def test_trace_any_bit_exact(ctx, yk, oracle, name):
     assert 0.05 < want.mean() < 0.95
 
 
+@pytest.mark.parametrize("option,value", [("wide_bvh", 1), ("top_nodes", 0)])
+@pytest.mark.parametrize("name", ["cornell", "city-small"])
+def test_trace_layout_options_bit_exact(yk, oracle, name, option, value):
+    """4-wide collapsed nodes / no LDS-resident tree top: same hits (ids — hence exact-t tie
+    winners — and t) for random rays incl. axis-aligned ones, closest and any-hit."""
+    c = yk.Context(0, **{option: value})
+    try:
+        sd = scenes.by_name(name)
+        sc = yk.Scene(c, sd)
+        osc = oracle.OracleScene(sd)
+        o, d = _random_rays(sd, 60000, 11)
+        got, want = sc.intersect(o, d), osc.intersect(o, d)
+        assert np.array_equal(got["shape"], want["shape"])
+        hit = want["shape"] >= 0
+        assert np.array_equal(_bits(got["t"][hit]), _bits(want["t"][hit]))
+        tm = (np.abs(np.random.default_rng(4).normal(1.0, 0.7, o.shape[0])) + 0.01).astype(np.float32)
+        assert np.array_equal(sc.intersect(o, d, t_max=tm)["shape"], osc.intersect(o, d, t_max=tm)["shape"])
+        rng = np.random.default_rng(6)
+        ds = (d * rng.uniform(0.2, 3.0, (o.shape[0], 1))).astype(np.float32)
+        t1 = np.full(o.shape[0], 0.9999, dtype=np.float32)
+        al = rng.integers(-1, max(1, len(sd.lights)), o.shape[0]).astype(np.int32)
+        assert np.array_equal(sc.any_intersect(o, ds, t1, al), osc.any_intersect(o, ds, t1, al))
+    finally:
+        c.close()
+
+
 MATERIALS = [
     dict(kind=abi.MAT_MATTE, a=(0.7, 0.5, 0.3), c=0.0),
     dict(kind=abi.MAT_MATTE, a=(0.7, 0.5, 0.3), c=0.349),

@@ -49,9 +49,9 @@ template <int MODE> __global__ __launch_bounds__(256, 6) void k(const float4* __
 }
 
 int main(int argc, char** argv) {
-    size_t mb = argc > 1 ? atoi(argv[1]) : 64;
+    size_t kb = argc > 1 ? atoi(argv[1]) : 65536; size_t mb = kb / 1024;
     unsigned iters = argc > 2 ? atoi(argv[2]) : 2000;
-    unsigned n_rec = (unsigned)(mb * 1024 * 1024 / 64);
+    unsigned n_rec = (unsigned)(kb * 1024 / 64);
     float4* table;
     float* out;
     hipMalloc(&table, (size_t)n_rec * 64);
@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
             hipEventSynchronize(b);
             float ms;
             hipEventElapsedTime(&ms, a, b);
-            if (rep) printf("table %zu MB mode %d: %.3f ms  %.2f G records/s  %.2f TB/s\n", mb, mode, ms, (double)grid * 256 * iters / ms * 1e-6, (double)grid * 256 * iters * 64 / ms * 1e-9);
+            if (rep) printf("table %zu KB (%zu MB) mode %d: %.3f ms  %.2f G records/s  %.2f TB/s\n", kb, mb, mode, ms, (double)grid * 256 * iters / ms * 1e-6, (double)grid * 256 * iters * 64 / ms * 1e-9);
         }
     }
     return 0;

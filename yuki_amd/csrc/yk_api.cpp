@@ -52,6 +52,8 @@ struct yk_context {
     int n_cu = 256;
     // options
     int64_t batch_paths = 128 << 20;
+    int64_t wide_bvh = 0;   // traverse the 4-wide collapse of the BVH (scenes created afterwards)
+    int64_t top_nodes = YK_TOP_MAX; // interior nodes (capped by what the kernels were built for) of the first tree levels the traversal kernels keep in LDS
     int64_t sample_buf_cap = (int64_t)64 << 30;
     int64_t time_kernels = 1;
     int64_t streams = 2;  // batches in flight (1 or 2): the second stream's launches fill the first one's tails
@@ -72,11 +74,12 @@ typedef yk_context::WorkSet WorkSet;
 
 struct yk_scene {
     yk_context* ctx = nullptr;
+    int device = -1;  // copied: a scene may outlive its context (its buffers belong to the device)
     HostBvh bvh;
     uint32_t n_triangles = 0, n_spheres = 0, n_lights = 0;
     yk_scene_info info;
     // device
-    DevBuf nodes, tris, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights, spheres, texels, tex_info;
+    DevBuf nodes, nodes4, top_nodes, tris, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights, spheres, texels, tex_info;
     DevScene dev;
     bool on_device = false;
 };
@@ -144,6 +147,8 @@ yk_status yk_context_create(int device, yk_context** out) {
         return YK_ERR_DEVICE;
     }
     ctx->ws[0].stream = ctx->stream;
+    if (const char* w = std::getenv("YK_WIDE_BVH")) ctx->wide_bvh = std::atoi(w) != 0;  // experiments; same as set_option("wide_bvh")
+    if (const char* w = std::getenv("YK_TOP_NODES")) ctx->top_nodes = std::min(std::max(std::atoi(w), 0), YK_TOP_MAX);
     *out = ctx;
     return YK_OK;
 }
@@ -187,6 +192,11 @@ yk_status yk_context_set_option(yk_context* ctx, const char* key, int64_t value)
     } else if (k == "streams") {
         if (value < 1 || value > 2) return YK_ERR_INVALID_ARGUMENT;
         ctx->streams = value;
+    } else if (k == "top_nodes") {
+        if (value < 0 || value > YK_TOP_MAX) return YK_ERR_INVALID_ARGUMENT;
+        ctx->top_nodes = value;
+    } else if (k == "wide_bvh") {
+        ctx->wide_bvh = value != 0;
     } else if (k == "time_kernels") {
         ctx->time_kernels = value;
     } else {
@@ -379,6 +389,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
 
     yk_scene* s = new yk_scene();
     s->ctx = ctx;
+    s->device = ctx ? ctx->device : -1;
     s->n_triangles = d->n_triangles;
     s->n_spheres = d->n_spheres;
     s->n_lights = d->n_lights;
@@ -459,6 +470,10 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
             interior_index[i] = cnt;
             if (!nodes[i].is_leaf) ++cnt;
         }
+        if (nodes.size() > YK_REF_INDEX_MAX || s->bvh.shape_order.size() > YK_REF_INDEX_MAX) {
+            yk_scene_destroy(s);
+            return fail(ctx, YK_ERR_UNSUPPORTED, "more than 2^28 BVH nodes or shapes");
+        }
         auto ref_of = [&](uint32_t idx) -> uint32_t { return nodes[idx].is_leaf ? (YK_LEAF_BIT | nodes[idx].a) : interior_index[idx]; };
         std::vector<DevNode> dn(std::max<size_t>(n_interior, 1));
         for (size_t i = 0; i < nodes.size(); ++i) {
@@ -469,7 +484,95 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
             o.q0 = make_float4(c0.bmin[0], c0.bmin[1], c0.bmin[2], c0.bmax[0]);
             o.q1 = make_float4(c0.bmax[1], c0.bmax[2], c1.bmin[0], c1.bmin[1]);
             o.q2 = make_float4(c1.bmin[2], c1.bmax[0], c1.bmax[1], c1.bmax[2]);
-            o.q3 = make_uint4(ref_of((uint32_t)i + 1), ref_of(nodes[i].a), nodes[i].axis, 0u);
+            o.q3 = make_uint4(ref_of((uint32_t)i + 1), ref_of(nodes[i].a) | ((uint32_t)nodes[i].axis << YK_AXIS_SHIFT), 0u, 0u);
+        }
+        // top of the tree, breadth first, for the LDS-resident copy (YK_TOP_BIT refs)
+        std::vector<DevNode> top;
+        if (!nodes[0].is_leaf && ctx->top_nodes > 0) {
+            std::vector<uint32_t> order;  // reference node indices, breadth first
+            std::vector<uint32_t> top_id(nodes.size(), 0xffffffffu);
+            order.push_back(0);
+            top_id[0] = 0;
+            const size_t cap = (size_t)std::min<int64_t>(ctx->top_nodes, trace_top_nodes());
+            for (size_t q = 0; q < order.size() && order.size() < cap; ++q) {
+                const uint32_t P = order[q];
+                for (uint32_t c : {P + 1, nodes[P].a}) {
+                    if (!nodes[c].is_leaf && order.size() < cap) {
+                        top_id[c] = (uint32_t)order.size();
+                        order.push_back(c);
+                    }
+                }
+            }
+            for (uint32_t P : order) {
+                DevNode t = dn[interior_index[P]];
+                const uint32_t c0 = P + 1, c1 = nodes[P].a;
+                if (top_id[c0] != 0xffffffffu) t.q3.x = YK_TOP_BIT | top_id[c0];
+                if (top_id[c1] != 0xffffffffu) t.q3.y = YK_TOP_BIT | top_id[c1] | ((uint32_t)nodes[P].axis << YK_AXIS_SHIFT);
+                top.push_back(t);
+            }
+        }
+        // 4-wide collapse (DevNode4): one node per reference interior node reached at even depth
+        // below the root.  Built only while the traversal stack of the collapsed tree is
+        // guaranteed to fit (the reference asserts on its own stack depth, bvh.rs:172-174).
+        std::vector<DevNode4> dn4;
+        const bool wide = ctx->wide_bvh != 0 && !nodes[0].is_leaf && s->bvh.depth <= 64;
+        if (wide) {
+            dn4.reserve(n_interior / 2 + 1);
+            struct Todo {
+                uint32_t binary;  // reference node index of P
+                uint32_t slot;    // DevNode4 index to fill
+            };
+            std::vector<Todo> stack;
+            dn4.emplace_back();
+            stack.push_back(Todo{0u, 0u});
+            while (!stack.empty()) {
+                const Todo td = stack.back();
+                stack.pop_back();
+                const uint32_t P = td.binary, A = P + 1, B = nodes[P].a;
+                uint32_t child[4] = {YK_REF_NONE, YK_REF_NONE, YK_REF_NONE, YK_REF_NONE};  // reference node index per slot
+                if (nodes[A].is_leaf) {
+                    child[0] = A;
+                } else {
+                    child[0] = A + 1;
+                    child[1] = nodes[A].a;
+                }
+                if (nodes[B].is_leaf) {
+                    child[2] = B;
+                } else {
+                    child[2] = B + 1;
+                    child[3] = nodes[B].a;
+                }
+                float box[4][6] = {};
+                uint32_t ref[4];
+                for (int k = 0; k < 4; ++k) {
+                    ref[k] = YK_REF_NONE;
+                    if (child[k] == YK_REF_NONE) continue;
+                    const yk_bvh_node& c = nodes[child[k]];
+                    for (int a = 0; a < 3; ++a) {
+                        box[k][a] = c.bmin[a];
+                        box[k][3 + a] = c.bmax[a];
+                    }
+                    if (c.is_leaf) {
+                        ref[k] = YK_LEAF_BIT | c.a;
+                    } else {
+                        ref[k] = (uint32_t)dn4.size();
+                        dn4.emplace_back();
+                    }
+                }
+                // children are expanded so that the first visited subtree (for a positive ray) follows in memory
+                for (int k = 3; k >= 0; --k)
+                    if (ref[k] != YK_REF_NONE && !(ref[k] & YK_LEAF_BIT)) stack.push_back(Todo{child[k], ref[k]});
+                DevNode4& o = dn4[td.slot];
+                o.q0 = make_float4(box[0][0], box[0][1], box[0][2], box[0][3]);
+                o.q1 = make_float4(box[0][4], box[0][5], box[1][0], box[1][1]);
+                o.q2 = make_float4(box[1][2], box[1][3], box[1][4], box[1][5]);
+                o.q3 = make_float4(box[2][0], box[2][1], box[2][2], box[2][3]);
+                o.q4 = make_float4(box[2][4], box[2][5], box[3][0], box[3][1]);
+                o.q5 = make_float4(box[3][2], box[3][3], box[3][4], box[3][5]);
+                o.q6 = make_uint4(ref[0], ref[1], ref[2], ref[3]);
+                const uint32_t axA = nodes[A].is_leaf ? 0u : nodes[A].axis, axB = nodes[B].is_leaf ? 0u : nodes[B].axis;
+                o.q7 = make_uint4((uint32_t)nodes[P].axis | (axA << 2) | (axB << 4), 0u, 0u, 0u);
+            }
         }
         const size_t np = s->bvh.shape_order.size();
         std::vector<float4> tris(3 * np);
@@ -534,6 +637,8 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         return st;                                        \
     }
         UP(nodes, dn.data(), dn.size());
+        UP(nodes4, dn4.data(), dn4.size());
+        UP(top_nodes, top.data(), top.size());
         UP(tris, tris.data(), tris.size());
         UP(indices, d->indices, 3 * (size_t)d->n_triangles);
         UP(points, d->points, 3 * (size_t)d->n_vertices);
@@ -563,6 +668,9 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
 #undef UP
         DevScene& ds = s->dev;
         ds.nodes = s->nodes.as<DevNode>();
+        ds.nodes4 = wide ? s->nodes4.as<DevNode4>() : nullptr;
+        ds.top_nodes = s->top_nodes.as<DevNode>();
+        ds.n_top = (uint32_t)top.size();
         ds.tris = s->tris.as<float4>();
         ds.spheres = d->n_spheres ? s->spheres.as<DevSphere>() : nullptr;
         ds.n_triangles = d->n_triangles;
@@ -587,7 +695,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         ds.tex_info = d->n_textures ? s->tex_info.as<uint4>() : nullptr;
         s->on_device = true;
         s->info.upload_seconds = now_seconds() - u0;
-        DevBuf* all[] = {&s->nodes, &s->tris, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
+        DevBuf* all[] = {&s->nodes, &s->nodes4, &s->top_nodes, &s->tris, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
                          &s->mesh_flags, &s->materials, &s->lights, &s->spheres, &s->texels, &s->tex_info};
         for (DevBuf* b : all) s->info.device_bytes += b->bytes;
     }
@@ -597,8 +705,8 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
 
 void yk_scene_destroy(yk_scene* s) {
     if (!s) return;
-    if (s->ctx) (void)hipSetDevice(s->ctx->device);
-    DevBuf* all[] = {&s->nodes, &s->tris, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
+    if (s->device >= 0) (void)hipSetDevice(s->device);
+    DevBuf* all[] = {&s->nodes, &s->nodes4, &s->top_nodes, &s->tris, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
                      &s->mesh_flags, &s->materials, &s->lights, &s->spheres, &s->texels, &s->tex_info};
     for (DevBuf* b : all) b->release();
     delete s;
@@ -715,7 +823,8 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
     unsigned* ctrl = ws.ctrl.as<unsigned>();
     const DevScene& ds = scene->dev;
     const unsigned tg = trace_grid(ctx);
-    const unsigned sg = (unsigned)ctx->n_cu * 8u;
+    static const unsigned shade_bpc = std::getenv("YK_SHADE_BPC") ? (unsigned)std::atoi(std::getenv("YK_SHADE_BPC")) : 8u;
+    const unsigned sg = (unsigned)ctx->n_cu * shade_bpc;
     unsigned cur = 0;
     for (unsigned b = 0; b < prm.max_depth; ++b) {
         PathBuffers pc = path_buffers(ws, (int)cur), pn = path_buffers(ws, (int)(cur ^ 1u));

@@ -30,8 +30,8 @@ namespace yk {
 // BVH interior node, 64 B: both children's AABBs (exact f32 copies of the
 // reference's 32-byte nodes' bounds, bvh.rs:536-556) + child references.
 //   q0 = (c0.min.xyz, c0.max.x) q1 = (c0.max.yz, c1.min.xy) q2 = (c1.min.z, c1.max.xyz)
-//   q3 = (ref0, ref1, split_axis, 0); ref: bit31 set -> leaf, low bits = first primitive
-//                                          else index of an interior node
+//   q3 = (ref0, ref1 | split_axis << 28, 0, 0); ref: bit31 set -> leaf, low 28 bits = first
+//        primitive, else index of an interior node (bit 30: in DevScene::top_nodes)
 struct DevNode {
     float4 q0, q1, q2;
     uint4 q3;
@@ -39,6 +39,29 @@ struct DevNode {
 static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
 
 #define YK_LEAF_BIT 0x80000000u
+#define YK_REF_NONE 0xffffffffu
+#define YK_AXIS_SHIFT 28
+#define YK_AXIS_MASK (3u << YK_AXIS_SHIFT)
+#define YK_REF_INDEX_MAX ((1u << YK_AXIS_SHIFT) - 1u)
+// ref bit 30: index into DevScene::top_nodes (the first levels of the tree, which the
+// traversal kernels keep in LDS) instead of DevScene::nodes
+#define YK_TOP_BIT 0x40000000u
+#define YK_TOP_MAX 255
+
+// 128-byte (one cache line) 4-wide node: a reference interior node P collapsed with its two
+// children A = P+1 and B = second child.  Slots 0,1 = A's children (or A itself + NONE when
+// A is a leaf), slots 2,3 = B's.  Box i = (q[..]) packed like DevNode, twice.  The three
+// split axes give the reference's visiting order for a ray: B's group first when the
+// direction is negative along P's axis, and within a group the second child first when it is
+// negative along that child's axis (bvh.rs:184-194 applied at both levels).
+//   q0..q2 = boxes of slots 0,1   q3..q5 = boxes of slots 2,3
+//   q6 = refs (leaf bit | first primitive, index of a DevNode4, or YK_REF_NONE)
+//   q7 = (axis_P | axis_A << 2 | axis_B << 4, 0, 0, 0)
+struct DevNode4 {
+    float4 q0, q1, q2, q3, q4, q5;
+    uint4 q6, q7;
+};
+static_assert(sizeof(DevNode4) == 128, "DevNode4 must be 128 bytes");
 
 // Light record (lights/*.rs).  n of a rectangular light is constant
 // (sample_to_world * Normal(0,-1,0), rectangular_light.rs:48) and precomputed.
@@ -75,6 +98,9 @@ struct DevSphere {
 
 struct DevScene {
     const DevNode* nodes;
+    const DevNode4* nodes4;  // 4-wide collapse of the same tree (null: use `nodes`), root = entry 0
+    const DevNode* top_nodes;  // breadth-first copy of the first n_top interior nodes; child refs carry YK_TOP_BIT inside the set
+    uint32_t n_top;
     const float4* tris;  // 3 per primitive in leaf order: (p0, bits(area_light)) (p1, bits(source shape)) (p2, bits(YK_PRIM_*))
     const DevSphere* spheres;  // source shape s >= n_triangles is spheres[s - n_triangles]
     uint32_t n_triangles;

@@ -8,6 +8,7 @@ namespace yk {
 
 unsigned trace_block_size();
 unsigned trace_spill_depth();
+unsigned trace_top_nodes();
 unsigned trace_blocks_per_cu();
 
 void launch_pixel_table(hipStream_t s, const yk_tile* tiles, const uint32_t* tile_offset, uint32_t n_tiles, uint32_t n_pixels, uint32_t* pixel_xy,

@@ -113,6 +113,12 @@ __global__ void k_raygen_user(RenderParams prm, const float* ray_o, const float*
 // per append saturated the counter word (~90 M atomics/s, MI355X_MICROARCH.md
 // "dequeue") and made this kernel atomic-bound (profiles/r01_a_*: 0.178 s/frame,
 // 79 % of wave cycles waiting).
+#ifndef SHADE_CAP
+#define SHADE_CAP 512  // staged entries per block (paths and shadow rays each)
+#endif
+#ifndef SHADE_MIN_WAVES
+#define SHADE_MIN_WAVES 1  // waves per SIMD the register allocator must leave room for (blocks of 256 threads)
+#endif
 template <int CAP> struct ShadeStaging {
     float4 pO[CAP], pD[CAP], pT[CAP];
     uint4 pR[CAP];
@@ -133,7 +139,7 @@ __device__ __forceinline__ unsigned block_append(bool want, unsigned* lds_fill) 
 }
 
 template <int BLOCK, int CAP>
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
+__global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                                                  PathBuffers cur, PathBuffers nxt,
                                                  const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis,
                                                  unsigned* shq, unsigned* ctrl, unsigned cur_slot) {
@@ -539,7 +545,7 @@ void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const Render
                   PathBuffers cur, PathBuffers nxt,
                   const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis, unsigned* shq, unsigned* ctrl,
                   unsigned cur_slot) {
-    hipLaunchKernelGGL((k_shade<256, 512>), dim3(grid), dim3(256), 0, s, sc, prm, pixel_xy, sample_index_tab, cur, nxt, hit_tri, pend, shO, shD, shC, vis, shq, ctrl, cur_slot);
+    hipLaunchKernelGGL((k_shade<256, SHADE_CAP>), dim3(grid), dim3(256), 0, s, sc, prm, pixel_xy, sample_index_tab, cur, nxt, hit_tri, pend, shO, shD, shC, vis, shq, ctrl, cur_slot);
 }
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
                        const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* ctrl, unsigned cur_slot) {

@@ -21,7 +21,10 @@
 #define TRACE_BLOCK 256
 #endif
 #ifndef TRACE_LDS
-#define TRACE_LDS 12  // stack entries per lane kept in LDS
+#define TRACE_LDS 10  // stack entries per lane kept in LDS
+#endif
+#ifndef TRACE_TOP
+#define TRACE_TOP 95  // interior nodes of the first tree levels kept in LDS (<= YK_TOP_MAX)
 #endif
 #ifndef TRACE_MIN_WAVES
 #define TRACE_MIN_WAVES 6  // waves per SIMD the register allocator must leave room for
@@ -56,7 +59,8 @@ __device__ __forceinline__ void yk_experiment_node(const void* p, float sink) {
 // Traversal stack: entries [0, LDS_DEPTH) live in LDS laid out [depth][thread]
 // (conflict-free: the bank depends on the lane only), deeper entries overflow to
 // a per-thread slice of HBM scratch.  Capacity 64 like the reference (bvh.rs:172).
-#define YK_STACK_CAP 64
+#define YK_REF_STACK_CAP 64  // the reference's to_visit_stack (bvh.rs:172-174): binary traversal
+#define YK_STACK_CAP 96      // storage: 64 binary entries can become 96 in the 4-wide traversal
 
 // LDS words are addressed through an address_space(3) pointer so the compiler
 // emits ds_read_b64 / ds_write_b64 (a generic pointer in a struct degrades to
@@ -92,16 +96,86 @@ struct NodeBoxes {
 __device__ __forceinline__ NodeBoxes load_node(const DevNode* nodes, unsigned idx) {
     const float4* q = reinterpret_cast<const float4*>(nodes + idx);
     float4 a = q[0], b = q[1], c = q[2];
-    uint4 d = reinterpret_cast<const uint4*>(q)[3];
+    uint2 d = reinterpret_cast<const uint2*>(q)[6];  // only 56 of the node's 64 bytes are fetched
     NodeBoxes n;
     n.lo0 = V3{a.x, a.y, a.z};
     n.hi0 = V3{a.w, b.x, b.y};
     n.lo1 = V3{b.z, b.w, c.x};
     n.hi1 = V3{c.y, c.z, c.w};
     n.ref0 = d.x;
-    n.ref1 = d.y;
-    n.axis = d.z;
+    n.ref1 = d.y & ~YK_AXIS_MASK;
+    n.axis = (d.y >> YK_AXIS_SHIFT) & 3u;
     return n;
+}
+
+// the first tree levels live in LDS (YK_TOP_BIT refs): a block copies them once
+typedef __attribute__((address_space(3))) float4 lds_f4;
+__device__ __forceinline__ NodeBoxes load_node_lds(const float4* top, unsigned idx) {
+    const float4* q = top + 4 * idx;
+    float4 a = q[0], b = q[1], c = q[2];
+    uint2 d = reinterpret_cast<const uint2*>(q)[6];  // only 56 of the node's 64 bytes are fetched
+    NodeBoxes n;
+    n.lo0 = V3{a.x, a.y, a.z};
+    n.hi0 = V3{a.w, b.x, b.y};
+    n.lo1 = V3{b.z, b.w, c.x};
+    n.hi1 = V3{c.y, c.z, c.w};
+    n.ref0 = d.x;
+    n.ref1 = d.y & ~YK_AXIS_MASK;
+    n.axis = (d.y >> YK_AXIS_SHIFT) & 3u;
+    return n;
+}
+template <int BLOCK> __device__ __forceinline__ void fill_top(float4* lds_top, const DevScene& sc) {
+    const float4* src = reinterpret_cast<const float4*>(sc.top_nodes);
+    for (unsigned i = threadIdx.x; i < sc.n_top * 4u; i += BLOCK) lds_top[i] = src[i];
+    __syncthreads();
+}
+
+// ---- 4-wide node step ------------------------------------------------------------
+// Tests the four grandchild boxes of a collapsed node and returns them in the reference's
+// visiting order for this ray (slot k of the result is visited before slot k+1); a missed
+// or absent slot has ref == YK_REF_NONE.
+//
+// Equivalence with the binary traversal (traversal equivalence): the reference
+// would first test the intermediate child box A (or B) and only then its children.  For
+// the slab test of bounds.rs:176-193 a box that contains another yields, axis by axis, an
+// interval that contains the other's ((p - o) * inv is monotone in p, min/max keep order and
+// drop the same NaNs), so hit(grandchild) implies hit(child) with any t_max: skipping the
+// intermediate test visits exactly the same leaves.  Deferred slots keep their entry
+// distance and are re-checked against the current t_max when popped, as in the 2-wide step.
+struct Step4 {
+    unsigned ref[4];
+    float t[4];
+};
+__device__ __forceinline__ Step4 node4_step(const DevNode4* nodes, unsigned idx, const V3& o, const V3& inv, float t_max, unsigned negmask) {
+    const float4* q = reinterpret_cast<const float4*>(nodes + idx);
+    const float4 a0 = q[0], a1 = q[1], a2 = q[2], b0 = q[3], b1 = q[4], b2 = q[5];
+    const uint4 refs = reinterpret_cast<const uint4*>(q)[6];
+    const unsigned axes = reinterpret_cast<const uint4*>(q)[7].x;
+    Step4 s;
+    bool h0 = slab(V3{a0.x, a0.y, a0.z}, V3{a0.w, a1.x, a1.y}, o, inv, t_max, s.t[0]);
+    bool h1 = slab(V3{a1.z, a1.w, a2.x}, V3{a2.y, a2.z, a2.w}, o, inv, t_max, s.t[1]);
+    bool h2 = slab(V3{b0.x, b0.y, b0.z}, V3{b0.w, b1.x, b1.y}, o, inv, t_max, s.t[2]);
+    bool h3 = slab(V3{b1.z, b1.w, b2.x}, V3{b2.y, b2.z, b2.w}, o, inv, t_max, s.t[3]);
+    s.ref[0] = h0 ? refs.x : YK_REF_NONE;  // an absent slot already holds YK_REF_NONE
+    s.ref[1] = h1 ? refs.y : YK_REF_NONE;
+    s.ref[2] = h2 ? refs.z : YK_REF_NONE;
+    s.ref[3] = h3 ? refs.w : YK_REF_NONE;
+    const bool sp = (negmask >> (axes & 3u)) & 1u, sa = (negmask >> ((axes >> 2) & 3u)) & 1u, sb = (negmask >> ((axes >> 4) & 3u)) & 1u;
+#define YK_CSWAP(c, i, j)                         \
+    {                                             \
+        const unsigned ri = s.ref[i], rj = s.ref[j]; \
+        const float ti = s.t[i], tj = s.t[j];     \
+        s.ref[i] = (c) ? rj : ri;                 \
+        s.ref[j] = (c) ? ri : rj;                 \
+        s.t[i] = (c) ? tj : ti;                   \
+        s.t[j] = (c) ? ti : tj;                   \
+    }
+    YK_CSWAP(sa, 0, 1)
+    YK_CSWAP(sb, 2, 3)
+    YK_CSWAP(sp, 0, 2)
+    YK_CSWAP(sp, 1, 3)
+#undef YK_CSWAP
+    return s;
 }
 
 // Closest hit with the reference's visiting order (near child first by the sign
@@ -142,7 +216,7 @@ __device__ __forceinline__ void traverse_closest(const DevScene& sc, V3 o, V3 d,
             if (STATS || far_hit) {
                 // with STATS the far child is pushed even when its box is missed so
                 // that the test is counted at pop time like the reference does
-                if (sp >= YK_STACK_CAP) {
+                if (sp >= YK_REF_STACK_CAP) {
                     atomicOr(err, 1u);
                     return;
                 }
@@ -276,12 +350,14 @@ struct ChunkCursor {
     }
 };
 
-template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int CHUNK, bool SPHERES, bool API>
+template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int CHUNK, bool SPHERES, bool API, bool WIDE>
 __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(DevScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
                                                             const float* __restrict__ t_max_opt, const unsigned* count_ptr, unsigned* head,
                                                             int* __restrict__ hit_tri, float4* __restrict__ hit_out, uint2* spill,
                                                             unsigned spill_stride, unsigned* ctrl, unsigned long long* ray_counter) {
     __shared__ unsigned long long lds_stack[LDS_DEPTH * BLOCK];
+    __shared__ float4 lds_top[WIDE ? 1 : TRACE_TOP * 4];
+    if (!WIDE) fill_top<BLOCK>(lds_top, sc);
     TravStack<BLOCK, LDS_DEPTH> stk;
     stk.lds = (lds_u64*)lds_stack;
     stk.spill = (glb_u64*)spill;
@@ -289,6 +365,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(Dev
     stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
     const unsigned n = *count_ptr;
     if (ray_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter, (unsigned long long)n);
+    const unsigned root = WIDE ? 0u : (sc.n_top ? YK_TOP_BIT : sc.root_ref);
     const V3 root_lo = V3{sc.root_bmin[0], sc.root_bmin[1], sc.root_bmin[2]}, root_hi = V3{sc.root_bmax[0], sc.root_bmax[1], sc.root_bmax[2]};
 
     ChunkCursor work;
@@ -318,7 +395,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(Dev
             float tmin;
             if (slab(root_lo, root_hi, r.o, r.inv, r.t_max, tmin)) {
                 active = true;
-                cur = sc.root_ref;
+                cur = root;
                 sp = 0;
                 best = -1;
             } else {
@@ -348,8 +425,38 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(Dev
         const bool on_node = active && !(cur & YK_LEAF_BIT);
         const unsigned n_leaf = (unsigned)__popcll(__ballot(on_leaf));
         if (__any(on_node) && n_leaf < (unsigned)LEAF_MIN) {
-            if (on_node) {
-                NodeBoxes nb = load_node(sc.nodes, cur);
+            if (WIDE) {
+                if (on_node) {
+                    Step4 st = node4_step(sc.nodes4, cur, r.o, r.inv, r.t_max, r.negmask);
+                    // push the later-visited hits (last first); the first one is entered right away
+                    unsigned next = YK_REF_NONE;
+                    float next_t = 0.0f;
+#pragma unroll
+                    for (int k = 3; k >= 0; --k) {
+                        if (st.ref[k] != YK_REF_NONE) {
+                            if (next != YK_REF_NONE) {
+                                if (sp >= YK_STACK_CAP) {
+                                    atomicOr(ctrl + YK_CTRL_ERR, 1u);
+                                    sp = 0;
+                                } else {
+                                    stk.push(sp, next, next_t);
+                                    ++sp;
+                                }
+                            }
+                            next = st.ref[k];
+                            next_t = st.t[k];
+                        }
+                    }
+                    if (next != YK_REF_NONE) {
+                        cur = next;  // no leaf was visited since the test: its result is final
+                    } else if (!pop_closest(stk, sp, r.t_max, cur)) {
+                        hit_tri[ray_i] = best;
+                        if (API && hit_out) hit_out[ray_i] = make_float4(best_hit.t, best_hit.b0, best_hit.b1, best_hit.b2);
+                        active = false;
+                    }
+                }
+            } else if (on_node) {
+                NodeBoxes nb = (cur & YK_TOP_BIT) ? load_node_lds(lds_top, cur & ~YK_TOP_BIT) : load_node(sc.nodes, cur);
                 YK_EXPERIMENT_NODE(sc.nodes + cur, nb);
                 float t0, t1;
                 bool h0 = slab(nb.lo0, nb.hi0, r.o, r.inv, r.t_max, t0);
@@ -360,7 +467,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(Dev
                 float far_t = swap ? t0 : t1;
                 if (near_hit) {
                     if (far_hit) {
-                        if (sp >= YK_STACK_CAP) {
+                        if (sp >= YK_REF_STACK_CAP) {
                             atomicOr(ctrl + YK_CTRL_ERR, 1u);
                             sp = 0;  // abandon this ray; the host reports YK_ERR_STACK_OVERFLOW
                         } else {
@@ -409,12 +516,14 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(Dev
 
 // Shadow rays: shO/shD are dense (compacted by `shade`); slot_of[k] is where the
 // verdict goes (vis[slot] = 2 when occluded); slot_of == NULL (API mode): vis[k] = 0/1.
-template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int CHUNK, bool SPHERES>
+template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int CHUNK, bool SPHERES, bool WIDE>
 __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScene sc, const float4* __restrict__ shO, const float4* __restrict__ shD,
                                                         const unsigned* __restrict__ slot_of, const unsigned* count_ptr, unsigned* head,
                                                         unsigned char* __restrict__ vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
                                                         unsigned long long* shadow_counter) {
     __shared__ unsigned long long lds_stack[LDS_DEPTH * BLOCK];
+    __shared__ float4 lds_top[WIDE ? 1 : TRACE_TOP * 4];
+    if (!WIDE) fill_top<BLOCK>(lds_top, sc);
     TravStack<BLOCK, LDS_DEPTH> stk;
     stk.lds = (lds_u64*)lds_stack;
     stk.spill = (glb_u64*)spill;
@@ -422,6 +531,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScen
     stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
     const unsigned n = *count_ptr;
     if (shadow_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(shadow_counter, (unsigned long long)n);
+    const unsigned root = WIDE ? 0u : (sc.n_top ? YK_TOP_BIT : sc.root_ref);
     const V3 root_lo = V3{sc.root_bmin[0], sc.root_bmin[1], sc.root_bmin[2]}, root_hi = V3{sc.root_bmax[0], sc.root_bmax[1], sc.root_bmax[2]};
 
     ChunkCursor work;
@@ -448,7 +558,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScen
             float tmin;
             if (slab(root_lo, root_hi, r.o, r.inv, r.t_max, tmin)) {
                 active = true;
-                cur = sc.root_ref;
+                cur = root;
                 sp = 0;
             } else if (!slot_of) {
                 vis[slot] = 0;
@@ -474,8 +584,38 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScen
         const bool on_node = active && !(cur & YK_LEAF_BIT);
         const unsigned n_leaf = (unsigned)__popcll(__ballot(on_leaf));
         if (__any(on_node) && n_leaf < (unsigned)LEAF_MIN) {
-            if (on_node) {
-                NodeBoxes nb = load_node(sc.nodes, cur);
+            if (WIDE) {
+                if (on_node) {
+                    // any-hit: the verdict does not depend on the visiting order; near-first finds occluders sooner
+                    Step4 st = node4_step(sc.nodes4, cur, r.o, r.inv, r.t_max, r.negmask);
+                    unsigned next = YK_REF_NONE;
+#pragma unroll
+                    for (int k = 3; k >= 0; --k) {
+                        if (st.ref[k] != YK_REF_NONE) {
+                            if (next != YK_REF_NONE) {
+                                if (sp >= YK_STACK_CAP) {
+                                    atomicOr(ctrl + YK_CTRL_ERR, 1u);
+                                    sp = 0;
+                                } else {
+                                    stk.push(sp, next, 0.0f);
+                                    ++sp;
+                                }
+                            }
+                            next = st.ref[k];
+                        }
+                    }
+                    if (next != YK_REF_NONE) {
+                        cur = next;
+                    } else if (sp > 0) {
+                        --sp;
+                        cur = stk.at(sp).x;
+                    } else {
+                        if (!slot_of) vis[slot] = 0;
+                        active = false;  // unoccluded
+                    }
+                }
+            } else if (on_node) {
+                NodeBoxes nb = (cur & YK_TOP_BIT) ? load_node_lds(lds_top, cur & ~YK_TOP_BIT) : load_node(sc.nodes, cur);
                 float t0, t1;
                 bool h0 = slab(nb.lo0, nb.hi0, r.o, r.inv, r.t_max, t0);
                 bool h1 = slab(nb.lo1, nb.hi1, r.o, r.inv, r.t_max, t1);
@@ -484,7 +624,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScen
                 bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
                 if (near_hit) {
                     if (far_hit) {
-                        if (sp >= YK_STACK_CAP) {
+                        if (sp >= YK_REF_STACK_CAP) {
                             atomicOr(ctrl + YK_CTRL_ERR, 1u);
                             sp = 0;
                         } else {
@@ -595,8 +735,9 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(DevScene sc, const floa
 
 unsigned trace_block_size() { return TRACE_BLOCK; }
 unsigned trace_spill_depth() { return YK_STACK_CAP - TRACE_LDS; }
+unsigned trace_top_nodes() { return TRACE_TOP; }
 unsigned trace_blocks_per_cu() {
-    unsigned by_lds = (160u * 1024u) / (TRACE_LDS * TRACE_BLOCK * 8u);
+    unsigned by_lds = (160u * 1024u) / (TRACE_LDS * TRACE_BLOCK * 8u + TRACE_TOP * 64u);
     unsigned by_waves = (unsigned)TRACE_MIN_WAVES * 256u / TRACE_BLOCK;
     return by_lds < by_waves ? by_lds : by_waves;
 }
@@ -609,26 +750,32 @@ void launch_trace_closest(hipStream_t s, unsigned grid, const DevScene& sc, cons
                            head, hit_tri, hit_out, stats_out, spill, spill_stride, ctrl, ray_counter);
     else {
         const bool api = t_max_opt != nullptr || hit_out != nullptr;
-#define YK_LAUNCH_CLOSEST(SPH, API)                                                                                                              \
-    hipLaunchKernelGGL((k_trace_closest_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, SPH, API>), dim3(grid), \
+#define YK_LAUNCH_CLOSEST(SPH, API, WIDE)                                                                                                              \
+    hipLaunchKernelGGL((k_trace_closest_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, SPH, API, WIDE>), dim3(grid), \
                        dim3(TRACE_BLOCK), 0, s, sc, rayO, rayD, t_max_opt, count_ptr, head, hit_tri, hit_out, spill, spill_stride, ctrl, ray_counter)
+#define YK_LAUNCH_CLOSEST_W(SPH, API) \
+    if (sc.nodes4) YK_LAUNCH_CLOSEST(SPH, API, true); else YK_LAUNCH_CLOSEST(SPH, API, false)
         if (sc.spheres) {
-            if (api) YK_LAUNCH_CLOSEST(true, true); else YK_LAUNCH_CLOSEST(true, false);
+            if (api) { YK_LAUNCH_CLOSEST_W(true, true); } else { YK_LAUNCH_CLOSEST_W(true, false); }
         } else {
-            if (api) YK_LAUNCH_CLOSEST(false, true); else YK_LAUNCH_CLOSEST(false, false);
+            if (api) { YK_LAUNCH_CLOSEST_W(false, true); } else { YK_LAUNCH_CLOSEST_W(false, false); }
         }
+#undef YK_LAUNCH_CLOSEST_W
 #undef YK_LAUNCH_CLOSEST
     }
 }
 void launch_trace_any(hipStream_t s, unsigned grid, const DevScene& sc, const float4* shO, const float4* shD, const unsigned* slot_of,
                       const unsigned* count_ptr, unsigned* head, unsigned char* vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
                       unsigned long long* shadow_counter) {
-    if (sc.spheres)
-        hipLaunchKernelGGL((k_trace_any_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, true>), dim3(grid), dim3(TRACE_BLOCK), 0,
-                           s, sc, shO, shD, slot_of, count_ptr, head, vis, spill, spill_stride, ctrl, shadow_counter);
-    else
-        hipLaunchKernelGGL((k_trace_any_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, false>), dim3(grid), dim3(TRACE_BLOCK), 0,
-                           s, sc, shO, shD, slot_of, count_ptr, head, vis, spill, spill_stride, ctrl, shadow_counter);
+#define YK_LAUNCH_ANY(SPH, WIDE)                                                                                                                       \
+    hipLaunchKernelGGL((k_trace_any_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, SPH, WIDE>), dim3(grid),     \
+                       dim3(TRACE_BLOCK), 0, s, sc, shO, shD, slot_of, count_ptr, head, vis, spill, spill_stride, ctrl, shadow_counter)
+    if (sc.spheres) {
+        if (sc.nodes4) YK_LAUNCH_ANY(true, true); else YK_LAUNCH_ANY(true, false);
+    } else {
+        if (sc.nodes4) YK_LAUNCH_ANY(false, true); else YK_LAUNCH_ANY(false, false);
+    }
+#undef YK_LAUNCH_ANY
 }
 
 }  // namespace yk
