@@ -183,11 +183,12 @@ def test_error_behaviour(ctx, yk):
     assert e.value.status == 7
 
 
-@pytest.mark.parametrize("option,value", [("wide_bvh", 1), ("top_nodes", 0), ("top_nodes", 7)])
+@pytest.mark.parametrize("option,value", [("wide_bvh", 1), ("top_nodes", 0), ("top_nodes", 7), ("packet_bounces", 0), ("packet_bounces", 8), ("packet_shadow_bounces", 8), ("overlap_shadow", 0)])
 def test_traversal_layout_options_do_not_change_the_image(yk, oracle, option, value):
-    """The optional traversal layouts — the 4-wide collapse of the BVH (DevNode4) and the
-    number of top-of-tree nodes kept in LDS — visit the same leaves in the same order, so the
-    render stays bit-identical to the oracle's (scene with triangles and spheres)."""
+    """The traversal variants — 4-wide collapse of the BVH (DevNode4), number of top-of-tree
+    nodes kept in LDS, wave-packet kernels for none / all bounces (closest and shadow rays),
+    side-stream overlap off — visit the same leaves in the same order per ray, so the render
+    stays bit-identical to the oracle's (scenes with triangles and spheres)."""
     c = yk.Context(0, **{option: value})
     try:
         for name, res in (("cornell", (64, 64)), ("city-tiny", (96, 54))):

@@ -52,6 +52,9 @@ struct yk_context {
     int n_cu = 256;
     // options
     int64_t batch_paths = 128 << 20;
+    int64_t packet_bounces = 1;         // leading bounces whose closest-hit rays use the wave-packet kernel (camera rays are coherent); 0 = never
+    int64_t packet_shadow_bounces = 0;  // same for their shadow rays (measured slower than the generic kernel on cfg3: off)
+    int64_t overlap_shadow = 1;  // run {trace_any, accumulate}(b) on a side stream beside trace_closest(b+1)
     int64_t wide_bvh = 0;   // traverse the 4-wide collapse of the BVH (scenes created afterwards)
     int64_t top_nodes = YK_TOP_MAX; // interior nodes (capped by what the kernels were built for) of the first tree levels the traversal kernels keep in LDS
     int64_t sample_buf_cap = (int64_t)64 << 30;
@@ -60,11 +63,12 @@ struct yk_context {
     // per-stream work buffers
     struct WorkSet {
         DevBuf path[2][4];
-        DevBuf hit, pend, shO, shD, shC, vis, shq, ctrl, spill;
+        DevBuf hit, pend, shO, shD, shC, vis, shq, ctrl, spill, spill_side;
         size_t cap_paths = 0;
         unsigned cap_lights = 0;
         hipStream_t stream = nullptr;
-        hipEvent_t done = nullptr;
+        hipStream_t side = nullptr;  // shadow rays + accumulate of bounce b run here beside trace of bounce b+1
+        hipEvent_t done = nullptr, ev_shade = nullptr, ev_acc = nullptr;
     } ws[2];
     DevBuf sample_buf, pixel_xy, tiles, tile_off, counters, stats4, hit4, scratch[8];
     std::vector<hipEvent_t> ev_pool;
@@ -142,12 +146,20 @@ yk_status yk_context_create(int device, yk_context** out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->ws[1].stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ws[0].done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ws[1].done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ws[1].done, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->ws[0].side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->ws[1].side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ws[0].ev_shade, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ws[1].ev_shade, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ws[0].ev_acc, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ws[1].ev_acc, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return YK_ERR_DEVICE;
     }
     ctx->ws[0].stream = ctx->stream;
     if (const char* w = std::getenv("YK_WIDE_BVH")) ctx->wide_bvh = std::atoi(w) != 0;  // experiments; same as set_option("wide_bvh")
+    if (const char* w = std::getenv("YK_PACKET_BOUNCES")) ctx->packet_bounces = std::max(std::atoi(w), 0);
+    if (const char* w = std::getenv("YK_PACKET_SHADOW_BOUNCES")) ctx->packet_shadow_bounces = std::max(std::atoi(w), 0);
     if (const char* w = std::getenv("YK_TOP_NODES")) ctx->top_nodes = std::min(std::max(std::atoi(w), 0), YK_TOP_MAX);
     *out = ctx;
     return YK_OK;
@@ -161,9 +173,15 @@ void yk_context_destroy(yk_context* ctx) {
     for (WorkSet& w : ctx->ws) {
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 4; ++b) w.path[a][b].release();
-        DevBuf* wb[] = {&w.hit, &w.pend, &w.shO, &w.shD, &w.shC, &w.vis, &w.shq, &w.ctrl, &w.spill};
+        DevBuf* wb[] = {&w.hit, &w.pend, &w.shO, &w.shD, &w.shC, &w.vis, &w.shq, &w.ctrl, &w.spill, &w.spill_side};
         for (DevBuf* b : wb) b->release();
         if (w.done) (void)hipEventDestroy(w.done);
+        if (w.ev_shade) (void)hipEventDestroy(w.ev_shade);
+        if (w.ev_acc) (void)hipEventDestroy(w.ev_acc);
+        if (w.side) {
+            (void)hipStreamSynchronize(w.side);
+            (void)hipStreamDestroy(w.side);
+        }
     }
     (void)hipStreamDestroy(ctx->ws[1].stream);
     DevBuf* all[] = {&ctx->sample_buf, &ctx->pixel_xy, &ctx->tiles, &ctx->tile_off, &ctx->counters, &ctx->stats4, &ctx->hit4};
@@ -192,6 +210,14 @@ yk_status yk_context_set_option(yk_context* ctx, const char* key, int64_t value)
     } else if (k == "streams") {
         if (value < 1 || value > 2) return YK_ERR_INVALID_ARGUMENT;
         ctx->streams = value;
+    } else if (k == "packet_bounces") {
+        if (value < 0) return YK_ERR_INVALID_ARGUMENT;
+        ctx->packet_bounces = value;
+    } else if (k == "packet_shadow_bounces") {
+        if (value < 0) return YK_ERR_INVALID_ARGUMENT;
+        ctx->packet_shadow_bounces = value;
+    } else if (k == "overlap_shadow") {
+        ctx->overlap_shadow = value != 0;
     } else if (k == "top_nodes") {
         if (value < 0 || value > YK_TOP_MAX) return YK_ERR_INVALID_ARGUMENT;
         ctx->top_nodes = value;
@@ -752,6 +778,7 @@ static unsigned trace_grid(const yk_context* ctx) { return (unsigned)ctx->n_cu *
 static yk_status ensure_spill(yk_context* ctx, WorkSet& ws) {
     size_t threads = (size_t)trace_grid(ctx) * trace_block_size();
     HIP_TRY(ctx, ws.spill.ensure(threads * trace_spill_depth() * 8));
+    HIP_TRY(ctx, ws.spill_side.ensure(threads * trace_spill_depth() * 8));
     return YK_OK;
 }
 
@@ -819,35 +846,61 @@ struct KernelTimer {
 
 // one batch of `n` paths already generated into buffer 0; runs the bounce loop
 static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* scene, const RenderParams& prm, const uint32_t* pixel_xy,
-                        const uint32_t* sample_index_tab, float4* sample_buf, KernelTimer& kt, unsigned long long* counters) {
+                        const uint32_t* sample_index_tab, float4* sample_buf, KernelTimer& kt, unsigned long long* counters, bool coherent) {
     unsigned* ctrl = ws.ctrl.as<unsigned>();
     const DevScene& ds = scene->dev;
     const unsigned tg = trace_grid(ctx);
+    const unsigned pg = (unsigned)ctx->n_cu * packet_blocks_per_cu();
     static const unsigned shade_bpc = std::getenv("YK_SHADE_BPC") ? (unsigned)std::atoi(std::getenv("YK_SHADE_BPC")) : 8u;
     const unsigned sg = (unsigned)ctx->n_cu * shade_bpc;
     unsigned cur = 0;
+    // Bounce b: trace_closest -> shade on `st`; then {trace_any, accumulate}(b) go to the side
+    // stream while `st` already traces bounce b+1 — two persistent kernels whose drained
+    // CUs are picked up by the other one (the tail of a small launch is one long ray).
+    // shade(b+1) overwrites what accumulate(b) reads (the other path buffer, pend, shC, vis,
+    // the shadow queue and its counter), so it waits for ev_acc.
+    const bool overlap = ctx->overlap_shadow != 0 && ws.side != nullptr;
+    hipStream_t sb = overlap ? ws.side : st;
     for (unsigned b = 0; b < prm.max_depth; ++b) {
         PathBuffers pc = path_buffers(ws, (int)cur), pn = path_buffers(ws, (int)(cur ^ 1u));
+        // camera rays (consecutive samples of a pixel) and the shadow rays they spawn are coherent:
+        // the wave walks the tree once for all 64 of them (yk_packet.hip)
+        const bool packet = coherent && b < (unsigned)ctx->packet_bounces && scene->bvh.depth <= 64;
+        const bool packet_shadow = coherent && b < (unsigned)ctx->packet_shadow_bounces && scene->bvh.depth <= 64;
+        int e = kt.begin(st);
+        if (packet)
+            launch_trace_closest_packet(st, pg, ds, pc.rayO, pc.rayD, ctrl + cur, ctrl + YK_CTRL_HEADS + 2 * b, ws.hit.as<int>(), counters);
+        else
+            launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, ctrl + cur, ctrl + YK_CTRL_HEADS + 2 * b, ws.hit.as<int>(), nullptr, nullptr,
+                                 ws.spill.as<uint2>(), tg * trace_block_size(), ctrl, counters);
+        kt.end(e, 0, st);
+        if (overlap && b > 0) (void)hipStreamWaitEvent(st, ws.ev_acc, 0);
         // reset the consumer-side counters of this bounce
         (void)hipMemsetAsync(ctrl + (cur ^ 1u), 0, 4, st);
         (void)hipMemsetAsync(ctrl + YK_CTRL_SHQ, 0, 4, st);
-        int e = kt.begin(st);
-        launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, ctrl + cur, ctrl + YK_CTRL_HEADS + 2 * b, ws.hit.as<int>(), nullptr, nullptr,
-                             ws.spill.as<uint2>(), tg * trace_block_size(), ctrl, counters);
-        kt.end(e, 0, st);
         e = kt.begin(st);
         launch_shade(st, sg, ds, prm, pixel_xy, sample_index_tab, pc, pn, ws.hit.as<int>(), ws.pend.as<float4>(), ws.shO.as<float4>(),
                      ws.shD.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ws.shq.as<unsigned>(), ctrl, cur);
         kt.end(e, 2, st);
-        e = kt.begin(st);
-        launch_trace_any(st, tg, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), ctrl + YK_CTRL_SHQ,
-                         ctrl + YK_CTRL_HEADS + 2 * b + 1, ws.vis.as<unsigned char>(), ws.spill.as<uint2>(), tg * trace_block_size(), ctrl,
-                         counters + 1);
-        kt.end(e, 1, st);
-        launch_accumulate(st, sg, prm, pc, ws.pend.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ds.n_lights, sample_buf, ctrl, cur);
+        if (overlap) {
+            (void)hipEventRecord(ws.ev_shade, st);
+            (void)hipStreamWaitEvent(sb, ws.ev_shade, 0);
+        }
+        e = kt.begin(sb);
+        if (packet_shadow)
+            launch_trace_any_packet(sb, pg, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), ctrl + YK_CTRL_SHQ,
+                                    ctrl + YK_CTRL_HEADS + 2 * b + 1, ws.vis.as<unsigned char>(), counters + 1);
+        else
+            launch_trace_any(sb, tg, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), ctrl + YK_CTRL_SHQ,
+                             ctrl + YK_CTRL_HEADS + 2 * b + 1, ws.vis.as<unsigned char>(), (overlap ? ws.spill_side : ws.spill).as<uint2>(),
+                             tg * trace_block_size(), ctrl, counters + 1);
+        kt.end(e, 1, sb);
+        launch_accumulate(sb, sg, prm, pc, ws.pend.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ds.n_lights, sample_buf, ctrl, cur);
+        if (overlap) (void)hipEventRecord(ws.ev_acc, sb);
         if (kt.on && std::getenv("YK_DEBUG_BOUNCES")) {  // per-bounce breakdown (synchronises; diagnostics only)
             unsigned h[4];
             (void)hipStreamSynchronize(st);
+            (void)hipStreamSynchronize(sb);
             (void)hipMemcpy(h, ctrl, 16, hipMemcpyDeviceToHost);
             float tt = 0, ts = 0, th = 0;
             (void)hipEventElapsedTime(&tt, ctx->ev_pool[kt.spans[0].back().first], ctx->ev_pool[kt.spans[0].back().second]);
@@ -858,6 +911,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         }
         cur ^= 1u;
     }
+    if (overlap) (void)hipStreamWaitEvent(st, ws.ev_acc, 0);  // the batch is complete on `st` once its last accumulate is
 }
 
 }  // extern "C"
@@ -991,7 +1045,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
             launch_raygen(bs, cam, prm, pixel_xy, pixel_sample, w0, n, path_buffers(ws, 0), sample_buf, ctrl);
             ++n_batches;
             if (is_path) {
-                run_bounces(ctx, ws, bs, scene, prm, pixel_xy, pixel_sample, sample_buf, kt, counters);
+                run_bounces(ctx, ws, bs, scene, prm, pixel_xy, pixel_sample, sample_buf, kt, counters, true);
                 n_trace += prm.max_depth;
             } else {
                 PathBuffers pc = path_buffers(ws, 0);
@@ -1197,7 +1251,7 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
     KernelTimer kt;
     kt.ctx = ctx;
     kt.on = false;
-    run_bounces(ctx, ctx->ws[0], st, scene, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), ctx->sample_buf.as<float4>(), kt, counters);
+    run_bounces(ctx, ctx->ws[0], st, scene, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), ctx->sample_buf.as<float4>(), kt, counters, false);
     HIP_TRY(ctx, hipGetLastError());
     std::vector<float> tmp(n * 4);
     HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->sample_buf.p, n * 16, hipMemcpyDeviceToHost, st));

@@ -9,6 +9,12 @@ namespace yk {
 unsigned trace_block_size();
 unsigned trace_spill_depth();
 unsigned trace_top_nodes();
+// wave-packet traversal for coherent rays (yk_packet.hip); requires tree depth <= 64
+unsigned packet_blocks_per_cu();
+void launch_trace_closest_packet(hipStream_t s, unsigned grid, const DevScene& sc, const float4* rayO, const float4* rayD, const unsigned* count_ptr,
+                                 unsigned* head, int* hit_tri, unsigned long long* ray_counter);
+void launch_trace_any_packet(hipStream_t s, unsigned grid, const DevScene& sc, const float4* shO, const float4* shD, const unsigned* slot_of,
+                             const unsigned* count_ptr, unsigned* head, unsigned char* vis, unsigned long long* shadow_counter);
 unsigned trace_blocks_per_cu();
 
 void launch_pixel_table(hipStream_t s, const yk_tile* tiles, const uint32_t* tile_offset, uint32_t n_tiles, uint32_t n_pixels, uint32_t* pixel_xy,
