@@ -53,7 +53,7 @@ struct yk_context {
     // options
     int64_t batch_paths = 128 << 20;
     int64_t packet_bounces = 1;         // leading bounces whose closest-hit rays use the wave-packet kernel (camera rays are coherent); 0 = never
-    int64_t packet_shadow_bounces = 0;  // same for their shadow rays (measured slower than the generic kernel on cfg3: off)
+    int64_t packet_shadow_bounces = 1;  // same for the shadow rays towards point / spot / distant lights (their own queue)
     int64_t overlap_shadow = 1;  // run {trace_any, accumulate}(b) on a side stream beside trace_closest(b+1)
     int64_t wide_bvh = 0;   // traverse the 4-wide collapse of the BVH (scenes created afterwards)
     int64_t top_nodes = YK_TOP_MAX; // interior nodes (capped by what the kernels were built for) of the first tree levels the traversal kernels keep in LDS
@@ -63,9 +63,9 @@ struct yk_context {
     // per-stream work buffers
     struct WorkSet {
         DevBuf path[2][4];
-        DevBuf hit, pend, shO, shD, shC, vis, shq, ctrl, spill, spill_side;
+        DevBuf hit, pend, shO, shD, shC, vis, shq, shO2, shD2, shq2, ctrl, spill, spill_side;
         size_t cap_paths = 0;
-        unsigned cap_lights = 0;
+        unsigned cap_lights = 0, cap_area = 0, cap_delta = 0;
         hipStream_t stream = nullptr;
         hipStream_t side = nullptr;  // shadow rays + accumulate of bounce b run here beside trace of bounce b+1
         hipEvent_t done = nullptr, ev_shade = nullptr, ev_acc = nullptr;
@@ -80,7 +80,7 @@ struct yk_scene {
     yk_context* ctx = nullptr;
     int device = -1;  // copied: a scene may outlive its context (its buffers belong to the device)
     HostBvh bvh;
-    uint32_t n_triangles = 0, n_spheres = 0, n_lights = 0;
+    uint32_t n_triangles = 0, n_spheres = 0, n_lights = 0, n_delta_lights = 0;
     yk_scene_info info;
     // device
     DevBuf nodes, nodes4, top_nodes, tris, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights, spheres, texels, tex_info;
@@ -173,7 +173,7 @@ void yk_context_destroy(yk_context* ctx) {
     for (WorkSet& w : ctx->ws) {
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 4; ++b) w.path[a][b].release();
-        DevBuf* wb[] = {&w.hit, &w.pend, &w.shO, &w.shD, &w.shC, &w.vis, &w.shq, &w.ctrl, &w.spill, &w.spill_side};
+        DevBuf* wb[] = {&w.hit, &w.pend, &w.shO, &w.shD, &w.shC, &w.vis, &w.shq, &w.shO2, &w.shD2, &w.shq2, &w.ctrl, &w.spill, &w.spill_side};
         for (DevBuf* b : wb) b->release();
         if (w.done) (void)hipEventDestroy(w.done);
         if (w.ev_shade) (void)hipEventDestroy(w.ev_shade);
@@ -419,6 +419,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
     s->n_triangles = d->n_triangles;
     s->n_spheres = d->n_spheres;
     s->n_lights = d->n_lights;
+    for (uint32_t l = 0; l < d->n_lights; ++l) s->n_delta_lights += d->lights[l].kind != YK_LIGHT_RECT ? 1u : 0u;
     std::memset(&s->info, 0, sizeof(s->info));
 
     // world bounds of every shape: Triangle::world_bound (triangle.rs:229-235),
@@ -752,24 +753,33 @@ yk_status yk_scene_export_bvh(const yk_scene* s, yk_bvh_node* nodes, uint32_t* s
 }
 
 // ------------------------------------------------------------------ render
-static yk_status ensure_work_buffers(yk_context* ctx, WorkSet& ws, size_t paths, unsigned n_lights) {
+static yk_status ensure_work_buffers(yk_context* ctx, WorkSet& ws, size_t paths, unsigned n_lights, unsigned n_delta_lights) {
     unsigned nl = std::max(1u, n_lights);
-    if (paths <= ws.cap_paths && nl <= ws.cap_lights) return YK_OK;
+    unsigned na = nl, nd = std::max(1u, n_delta_lights);  // queue 1 holds every light's rays on the bounces that are not split
+    if (paths <= ws.cap_paths && nl <= ws.cap_lights && na <= ws.cap_area && nd <= ws.cap_delta) return YK_OK;
     paths = std::max(paths, ws.cap_paths);
     nl = std::max(nl, ws.cap_lights);
+    na = std::max(na, ws.cap_area);
+    nd = std::max(nd, ws.cap_delta);
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 4; ++b) HIP_TRY(ctx, ws.path[a][b].ensure(paths * 16));
     HIP_TRY(ctx, ws.hit.ensure(paths * 4));
     HIP_TRY(ctx, ws.pend.ensure(paths * 16));
-    HIP_TRY(ctx, ws.shO.ensure(paths * nl * 16));
-    HIP_TRY(ctx, ws.shD.ensure(paths * nl * 16));
     HIP_TRY(ctx, ws.shC.ensure(paths * nl * 16));
     HIP_TRY(ctx, ws.vis.ensure(paths * nl));
-    HIP_TRY(ctx, ws.shq.ensure(paths * nl * 4));
+    // two shadow queues: rays towards area lights / towards point, spot and distant lights
+    HIP_TRY(ctx, ws.shO.ensure(paths * na * 16));
+    HIP_TRY(ctx, ws.shD.ensure(paths * na * 16));
+    HIP_TRY(ctx, ws.shq.ensure(paths * na * 4));
+    HIP_TRY(ctx, ws.shO2.ensure(paths * nd * 16));
+    HIP_TRY(ctx, ws.shD2.ensure(paths * nd * 16));
+    HIP_TRY(ctx, ws.shq2.ensure(paths * nd * 4));
     HIP_TRY(ctx, ws.ctrl.ensure(YK_CTRL_WORDS * 4));
     HIP_TRY(ctx, ctx->counters.ensure(64));
     ws.cap_paths = paths;
     ws.cap_lights = nl;
+    ws.cap_area = na;
+    ws.cap_delta = nd;
     return YK_OK;
 }
 
@@ -866,34 +876,44 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         // camera rays (consecutive samples of a pixel) and the shadow rays they spawn are coherent:
         // the wave walks the tree once for all 64 of them (yk_packet.hip)
         const bool packet = coherent && b < (unsigned)ctx->packet_bounces && scene->bvh.depth <= 64;
-        const bool packet_shadow = coherent && b < (unsigned)ctx->packet_shadow_bounces && scene->bvh.depth <= 64;
+        const bool packet_shadow = coherent && b < (unsigned)ctx->packet_shadow_bounces && scene->bvh.depth <= 64 && scene->n_delta_lights > 0;
+        // shadow rays are split into two queues only when the second one gets the packet kernel;
+        // otherwise everything goes to the first queue and one launch traces it
+        const bool split = packet_shadow && scene->n_lights > scene->n_delta_lights;
+        const bool all_delta = packet_shadow && !split;  // no area lights: the single queue is all coherent
         int e = kt.begin(st);
         if (packet)
-            launch_trace_closest_packet(st, pg, ds, pc.rayO, pc.rayD, ctrl + cur, ctrl + YK_CTRL_HEADS + 2 * b, ws.hit.as<int>(), counters);
+            launch_trace_closest_packet(st, pg, ds, pc.rayO, pc.rayD, ctrl + cur, ctrl + YK_CTRL_HEADS + 3 * b, ws.hit.as<int>(), counters);
         else
-            launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, ctrl + cur, ctrl + YK_CTRL_HEADS + 2 * b, ws.hit.as<int>(), nullptr, nullptr,
+            launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, ctrl + cur, ctrl + YK_CTRL_HEADS + 3 * b, ws.hit.as<int>(), nullptr, nullptr,
                                  ws.spill.as<uint2>(), tg * trace_block_size(), ctrl, counters);
         kt.end(e, 0, st);
         if (overlap && b > 0) (void)hipStreamWaitEvent(st, ws.ev_acc, 0);
         // reset the consumer-side counters of this bounce
         (void)hipMemsetAsync(ctrl + (cur ^ 1u), 0, 4, st);
         (void)hipMemsetAsync(ctrl + YK_CTRL_SHQ, 0, 4, st);
+        (void)hipMemsetAsync(ctrl + YK_CTRL_SHQ2, 0, 4, st);
         e = kt.begin(st);
         launch_shade(st, sg, ds, prm, pixel_xy, sample_index_tab, pc, pn, ws.hit.as<int>(), ws.pend.as<float4>(), ws.shO.as<float4>(),
-                     ws.shD.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ws.shq.as<unsigned>(), ctrl, cur);
+                     ws.shD.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ws.shq.as<unsigned>(), ws.shO2.as<float4>(),
+                     ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), ctrl, cur, split ? 1u : 0u);
         kt.end(e, 2, st);
         if (overlap) {
             (void)hipEventRecord(ws.ev_shade, st);
             (void)hipStreamWaitEvent(sb, ws.ev_shade, 0);
         }
         e = kt.begin(sb);
-        if (packet_shadow)
+        uint2* any_spill = (overlap ? ws.spill_side : ws.spill).as<uint2>();
+        if (all_delta) {
             launch_trace_any_packet(sb, pg, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), ctrl + YK_CTRL_SHQ,
-                                    ctrl + YK_CTRL_HEADS + 2 * b + 1, ws.vis.as<unsigned char>(), counters + 1);
-        else
+                                    ctrl + YK_CTRL_HEADS + 3 * b + 1, ws.vis.as<unsigned char>(), counters + 1);
+        } else {
             launch_trace_any(sb, tg, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), ctrl + YK_CTRL_SHQ,
-                             ctrl + YK_CTRL_HEADS + 2 * b + 1, ws.vis.as<unsigned char>(), (overlap ? ws.spill_side : ws.spill).as<uint2>(),
-                             tg * trace_block_size(), ctrl, counters + 1);
+                             ctrl + YK_CTRL_HEADS + 3 * b + 1, ws.vis.as<unsigned char>(), any_spill, tg * trace_block_size(), ctrl, counters + 1);
+            if (split)  // rays converging on a point / spot / distant light: wave packets
+                launch_trace_any_packet(sb, pg, ds, ws.shO2.as<float4>(), ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), ctrl + YK_CTRL_SHQ2,
+                                        ctrl + YK_CTRL_HEADS + 3 * b + 2, ws.vis.as<unsigned char>(), counters + 1);
+        }
         kt.end(e, 1, sb);
         launch_accumulate(sb, sg, prm, pc, ws.pend.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ds.n_lights, sample_buf, ctrl, cur);
         if (overlap) (void)hipEventRecord(ws.ev_acc, sb);
@@ -902,12 +922,14 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
             (void)hipStreamSynchronize(st);
             (void)hipStreamSynchronize(sb);
             (void)hipMemcpy(h, ctrl, 16, hipMemcpyDeviceToHost);
+            unsigned hq2 = 0;
+            (void)hipMemcpy(&hq2, ctrl + YK_CTRL_SHQ2, 4, hipMemcpyDeviceToHost);
             float tt = 0, ts = 0, th = 0;
             (void)hipEventElapsedTime(&tt, ctx->ev_pool[kt.spans[0].back().first], ctx->ev_pool[kt.spans[0].back().second]);
             (void)hipEventElapsedTime(&ts, ctx->ev_pool[kt.spans[1].back().first], ctx->ev_pool[kt.spans[1].back().second]);
             (void)hipEventElapsedTime(&th, ctx->ev_pool[kt.spans[2].back().first], ctx->ev_pool[kt.spans[2].back().second]);
             std::fprintf(stderr, "bounce %u: rays %u trace %.3f ms (%.0f Mray/s) | shadow rays %u %.3f ms (%.0f Mray/s) | shade %.3f ms | survivors %u\n", b, h[cur],
-                         tt, h[cur] / (tt * 1e3), h[YK_CTRL_SHQ], ts, h[YK_CTRL_SHQ] / (ts * 1e3), th, h[cur ^ 1u]);
+                         tt, h[cur] / (tt * 1e3), h[YK_CTRL_SHQ] + hq2, ts, (h[YK_CTRL_SHQ] + hq2) / (ts * 1e3), th, h[cur ^ 1u]);
         }
         cur ^= 1u;
     }
@@ -928,7 +950,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
     RenderParams prm;
     yk_status ps = make_params(ctx, sampler, integrator, prm);
     if (ps != YK_OK) return ps;
-    if (prm.integrator == YK_INTEGRATOR_PATH && prm.max_depth > (YK_CTRL_WORDS - YK_CTRL_HEADS) / 2)
+    if (prm.integrator == YK_INTEGRATOR_PATH && prm.max_depth > (YK_CTRL_WORDS - YK_CTRL_HEADS) / 3)
         return fail(ctx, YK_ERR_INVALID_ARGUMENT, "max_depth too large");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
@@ -968,13 +990,13 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         // keep the per-batch work buffers (148 + 53*n_lights bytes per path) within half of the free HBM
         size_t free_b = 0, total_b = 0;
         if (batch > ctx->ws[0].cap_paths && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t per_path = (148 + 53 * (size_t)std::max(1u, scene->n_lights)) * (size_t)n_ws;
+            const size_t per_path = (148 + 53 * (size_t)std::max(1u, scene->n_lights) + 36) * (size_t)n_ws;
             const size_t fit = (free_b / 2) / per_path;
             if (fit >= 65536 && batch > fit) batch = fit;
         }
     }
     for (int w = 0; w < n_ws; ++w) {
-        yk_status wb = ensure_work_buffers(ctx, ctx->ws[w], batch, scene->n_lights);
+        yk_status wb = ensure_work_buffers(ctx, ctx->ws[w], batch, scene->n_lights, scene->n_delta_lights);
         if (wb != YK_OK) return wb;
         if ((wb = ensure_spill(ctx, ctx->ws[w])) != YK_OK) return wb;
     }
@@ -1226,10 +1248,10 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
     yk_status ps = make_params(ctx, sampler, integrator, prm);
     if (ps != YK_OK) return ps;
     if (prm.integrator != YK_INTEGRATOR_PATH) return fail(ctx, YK_ERR_UNSUPPORTED, "yk_li implements the Path integrator");
-    if (prm.max_depth > (YK_CTRL_WORDS - YK_CTRL_HEADS) / 2) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "max_depth too large");
+    if (prm.max_depth > (YK_CTRL_WORDS - YK_CTRL_HEADS) / 3) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "max_depth too large");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    yk_status wb = ensure_work_buffers(ctx, ctx->ws[0], n, scene->n_lights);
+    yk_status wb = ensure_work_buffers(ctx, ctx->ws[0], n, scene->n_lights, scene->n_delta_lights);
     if (wb != YK_OK) return wb;
     if ((wb = ensure_spill(ctx, ctx->ws[0])) != YK_OK) return wb;
     HIP_TRY(ctx, ctx->scratch[4].ensure(n * 12));
@@ -1275,7 +1297,7 @@ yk_status yk_trace_closest(yk_context* ctx, const yk_scene* scene, size_t n, con
     if (n > 0xFFFFFF00ull) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many rays");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    yk_status wb = ensure_work_buffers(ctx, ctx->ws[0], n, scene->n_lights);
+    yk_status wb = ensure_work_buffers(ctx, ctx->ws[0], n, scene->n_lights, scene->n_delta_lights);
     if (wb != YK_OK) return wb;
     if ((wb = ensure_spill(ctx, ctx->ws[0])) != YK_OK) return wb;
     const bool want_stats = out_node_tests || out_node_hits || out_shape_tests;
@@ -1335,7 +1357,7 @@ yk_status yk_trace_any(yk_context* ctx, const yk_scene* scene, size_t n, const f
     if (n > 0xFFFFFF00ull) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many rays");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    yk_status wb = ensure_work_buffers(ctx, ctx->ws[0], n, scene->n_lights);
+    yk_status wb = ensure_work_buffers(ctx, ctx->ws[0], n, scene->n_lights, scene->n_delta_lights);
     if (wb != YK_OK) return wb;
     if ((wb = ensure_spill(ctx, ctx->ws[0])) != YK_OK) return wb;
     HIP_TRY(ctx, ctx->scratch[4].ensure(n * 12));
@@ -1395,7 +1417,7 @@ yk_status yk_camera_rays(yk_context* ctx, const yk_camera* camera, const yk_samp
     hipStream_t st = ctx->stream;
     const uint32_t npx = (uint32_t)(tile->x1 - tile->x0) * (uint32_t)(tile->y1 - tile->y0);
     const uint32_t spp = prm.sampler.spp;
-    yk_status wb = ensure_work_buffers(ctx, ctx->ws[0], (size_t)npx * spp, 1);
+    yk_status wb = ensure_work_buffers(ctx, ctx->ws[0], (size_t)npx * spp, 1, 0);
     if (wb != YK_OK) return wb;
     uint32_t off[2] = {0, npx};
     HIP_TRY(ctx, ctx->tiles.ensure(sizeof(yk_tile)));

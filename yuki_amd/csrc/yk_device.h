@@ -136,10 +136,11 @@ struct PathBuffers {
     uint4* rngs;
 };
 
-// control block, zeroed per batch: [0..1] active counts (ping-pong), [2] shadow queue
-// length, [3] error flags, [8+k] work-queue heads of the k-th launch of the batch
+// control block, zeroed per batch: [0..1] active counts (ping-pong), [2] and [4] shadow queue
+// lengths (area / delta lights), [3] error flags, [8+k] work-queue heads of the k-th launch
 #define YK_CTRL_WORDS 256
-#define YK_CTRL_SHQ 2
+#define YK_CTRL_SHQ 2   // shadow rays towards area lights (scattered directions)
+#define YK_CTRL_SHQ2 4  // shadow rays towards point / spot / distant lights (one target: coherent)
 #define YK_CTRL_ERR 3
 #define YK_CTRL_HEADS 8
 

@@ -125,6 +125,7 @@ template <int CAP> struct ShadeStaging {
     float4 qO[CAP], qD[CAP];
     unsigned qS[CAP];
     unsigned fill_p, fill_q, gbase;
+    unsigned q_delta;  // class of the staged shadow rays: 1 = towards a point/spot/distant light
 };
 
 // every thread of the block calls this (converged); returns the staging position
@@ -138,11 +139,13 @@ __device__ __forceinline__ unsigned block_append(bool want, unsigned* lds_fill) 
     return base + prefix;
 }
 
+__device__ __forceinline__ unsigned valid_light_kind(const DevScene& sc, unsigned l) { return sc.lights[l].kind; }
+
 template <int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                                                  PathBuffers cur, PathBuffers nxt,
                                                  const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis,
-                                                 unsigned* shq, unsigned* ctrl, unsigned cur_slot) {
+                                                 unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* ctrl, unsigned cur_slot, unsigned split_delta) {
     __shared__ ShadeStaging<CAP> stg;
     const unsigned n = ctrl[cur_slot];
     const unsigned nl = sc.n_lights;
@@ -151,17 +154,25 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
     if (threadIdx.x == 0) {
         stg.fill_p = 0;
         stg.fill_q = 0;
+        stg.q_delta = 0;
     }
     __syncthreads();
     // flush helpers (block-uniform control flow)
-    auto flush_q = [&](unsigned fill) {
-        if (threadIdx.x == 0) stg.gbase = atomicAdd(shq_count, fill);
+    // Shadow rays go to one of two queues: rays towards an area light leave a surface patch
+    // in scattered directions, rays towards a point / spot / distant light converge on one
+    // target and suit the wave-packet any-hit kernel.  The staging buffer only ever holds
+    // rays of one class (it is flushed when the class of the light changes).
+    auto flush_q = [&](unsigned fill, unsigned delta) {
+        if (threadIdx.x == 0) stg.gbase = atomicAdd(delta ? ctrl + YK_CTRL_SHQ2 : shq_count, fill);
         __syncthreads();
         const unsigned gb = stg.gbase;
+        float4* dO = delta ? shO2 : shO;
+        float4* dD = delta ? shD2 : shD;
+        unsigned* dS = delta ? shq2 : shq;
         for (unsigned k = threadIdx.x; k < fill; k += BLOCK) {
-            shO[gb + k] = stg.qO[k];
-            shD[gb + k] = stg.qD[k];
-            shq[gb + k] = stg.qS[k];
+            dO[gb + k] = stg.qO[k];
+            dD[gb + k] = stg.qD[k];
+            dS[gb + k] = stg.qS[k];
         }
         __syncthreads();
         if (threadIdx.x == 0) stg.fill_q = 0;
@@ -270,9 +281,11 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
             // contribution stays at its (path, light) slot for `accumulate`
             __syncthreads();
             {
-                const unsigned f = stg.fill_q;
+                const unsigned f = stg.fill_q, staged = stg.q_delta;
+                const unsigned delta = (split_delta && valid_light_kind(sc, l) != YK_LIGHT_RECT) ? 1u : 0u;
                 __syncthreads();  // every wave has read the same fill before any wave appends again
-                if (f + BLOCK > CAP) flush_q(f);
+                if (f && (staged != delta || f + BLOCK > CAP)) flush_q(f, staged);
+                if (threadIdx.x == 0) stg.q_delta = delta;
             }
             unsigned q = block_append(want, &stg.fill_q);
             if (want) {
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
     __syncthreads();
     {
         const unsigned fq = stg.fill_q, fp = stg.fill_p;
-        if (fq) flush_q(fq);
+        if (fq) flush_q(fq, stg.q_delta);
         if (fp) flush_p(fp);
     }
 }
@@ -543,9 +556,10 @@ void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, 
 }
 void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                   PathBuffers cur, PathBuffers nxt,
-                  const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis, unsigned* shq, unsigned* ctrl,
-                  unsigned cur_slot) {
-    hipLaunchKernelGGL((k_shade<256, SHADE_CAP>), dim3(grid), dim3(256), 0, s, sc, prm, pixel_xy, sample_index_tab, cur, nxt, hit_tri, pend, shO, shD, shC, vis, shq, ctrl, cur_slot);
+                  const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis, unsigned* shq, float4* shO2,
+                  float4* shD2, unsigned* shq2, unsigned* ctrl, unsigned cur_slot, unsigned split_delta) {
+    hipLaunchKernelGGL((k_shade<256, SHADE_CAP>), dim3(grid), dim3(256), 0, s, sc, prm, pixel_xy, sample_index_tab, cur, nxt, hit_tri, pend, shO, shD, shC, vis, shq,
+                       shO2, shD2, shq2, ctrl, cur_slot, split_delta);
 }
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
                        const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* ctrl, unsigned cur_slot) {
