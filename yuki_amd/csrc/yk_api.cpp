@@ -978,14 +978,11 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
     // Work is cut into batches of <= batch_paths camera samples.  With streams == 2
     // batches alternate between two work sets / HIP streams, so the latency-bound
     // tail launches of one batch (late bounces, few rays) run beside the bulk
-    // launches of the other.  A job that fits one batch is split in two halves.
+    // launches of the other.  A job that fits one batch stays on one work set: splitting it
+    // gains nothing once the side stream overlaps shadow rays with the next bounce (measured).
     const uint64_t total_work = total_px * spp;
-    // (a job that fills the GPU as ONE batch gains nothing from the split — measured —
-    // and keeps per-kernel timings unambiguous, so it stays on one stream)
     size_t batch = (size_t)std::min<uint64_t>((uint64_t)ctx->batch_paths, total_work);
-    const bool small_job = total_work >= (1u << 21) && total_work < (48u << 20);
-    const int n_ws = (ctx->streams >= 2 && is_path && !stream && (total_work > batch || small_job)) ? 2 : 1;
-    if (n_ws == 2 && batch * 2 > total_work) batch = (size_t)((total_work + 1) / 2);
+    const int n_ws = (ctx->streams >= 2 && is_path && !stream && total_work > batch) ? 2 : 1;
     {
         // keep the per-batch work buffers (148 + 53*n_lights bytes per path) within half of the free HBM
         size_t free_b = 0, total_b = 0;
