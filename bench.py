@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+GATHER_CEILING_GBPS = 14600.0
 HBM_COPY_CEILING_GBPS = 6290.0
 
 
@@ -169,7 +170,7 @@ def main():
     t0 = time.perf_counter()
     rays = shadow = 0
     t_trace = t_shadow = t_shade = t_dev = 0.0
-    launches = 0
+    launches = shadow_launches = 0
     for _ in range(args.steps):
         st = step()
         rays += st.rays
@@ -179,6 +180,7 @@ def main():
         t_shade += st.seconds_shade
         t_dev += st.seconds_total
         launches += st.trace_launches
+        shadow_launches += st.shadow_launches
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -212,11 +214,30 @@ def main():
             # whole-path figure of SURVEY §8(d): B_ray = 32*N_node + 36*N_tri + 304 with shadow tests attributed
             b_ray = 32.0 * (counters["node_tests_per_ray"] + counters["shadow_node_tests_per_ray"]) + 36.0 * (counters["shape_tests_per_ray"] + counters["shadow_shape_tests_per_ray"]) + 304.0
             pmc = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch") if os.path.exists(pmc) else None
-            roofline = dict(bound="hbm", kernel="k_trace_closest", achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s", frac=achieved / HBM_PEAK_GBPS,
-                            traffic=traffic, bytes_per_ray=b_closest, avg_launch_ms=t_trace / max(1, launches) * 1e3, launches=launches,
-                            rays_per_launch=rays / max(1, launches), frac_of_copy_ceiling=achieved / HBM_COPY_CEILING_GBPS,
-                            path_bytes_per_ray=b_ray, path_achieved=b_ray * (rays / max(t_dev, 1e-9)) / 1e9,
+            pmc_d = json.load(open(pmc)) if os.path.exists(pmc) else {}
+
+            def family(name, kernels, bytes_total, seconds, n_launch, units, traffic):
+                ach = bytes_total / max(seconds, 1e-12) / 1e9
+                return dict(bound="hbm", kernel=name, kernels=kernels, achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s", frac=ach / HBM_PEAK_GBPS, traffic=traffic,
+                            bytes_per_ray=bytes_total / max(1, units), avg_launch_ms=seconds / max(1, n_launch) * 1e3, launches=n_launch,
+                            rays_per_launch=units / max(1, n_launch), seconds_per_step=seconds / args.steps,
+                            frac_of_copy_ceiling=ach / HBM_COPY_CEILING_GBPS,
+                            # measured ceiling of per-lane 64-byte gathers from an L1/L2-resident table (tools/micro/gather_bench.hip,
+                            # DESIGN.md §4): the unit the traversal kernels are actually bound by
+                            frac_of_gather_ceiling=ach / GATHER_CEILING_GBPS)
+
+            # any-hit family: 32 B per node test + 36 B per triangle test of the shadow rays (the oracle's counters are per
+            # counted ray, so x rays) + 32 B ray read + 4 B slot per shadow ray
+            bytes_any = (32.0 * counters["shadow_node_tests_per_ray"] + 36.0 * counters["shadow_shape_tests_per_ray"]) * rays + 36.0 * shadow
+            fam_closest = family("k_trace_closest", ["k_trace_closest_pt", "k_trace_closest_packet"], b_closest * rays, t_trace, launches, rays,
+                                 pmc_d.get("closest", {}).get("hbm_bytes_per_launch", pmc_d.get("hbm_bytes_per_launch")))
+            fam_any = family("k_trace_any", ["k_trace_any_pt", "k_trace_any_packet"], bytes_any, t_shadow, shadow_launches, shadow,
+                             pmc_d.get("any", {}).get("hbm_bytes_per_launch"))
+            # the dominant kernel family is the one with the larger summed launch duration (HIP events on the launch streams;
+            # any-hit launches share the GPU with the next bounce's closest-hit launch, so their durations include that)
+            roofline, other = (fam_any, fam_closest) if t_shadow > t_trace else (fam_closest, fam_any)
+            roofline["other"] = other
+            roofline.update(path_bytes_per_ray=b_ray, path_achieved=b_ray * (rays / max(t_dev, 1e-9)) / 1e9,
                             path_frac=b_ray * (rays / max(t_dev, 1e-9)) / 1e9 / HBM_PEAK_GBPS)
         out = {
             "metric": "Mray/s (primary+secondary), Path integrator @1080p",

@@ -195,6 +195,7 @@ typedef struct yk_render_stats {
     double seconds_shadow;  /* summed duration of the any-hit traversal launches */
     double seconds_shade;   /* summed duration of the shade (BSDF+NEE) launches */
     uint32_t trace_launches, batches;
+    uint32_t shadow_launches, reserved; /* any-hit traversal launches (two on bounces whose shadow rays are split) */
 } yk_render_stats;
 
 typedef struct yk_context yk_context;

@@ -202,6 +202,8 @@ pub struct yk_render_stats {
     pub seconds_shade: f64,
     pub trace_launches: u32,
     pub batches: u32,
+    pub shadow_launches: u32,
+    pub reserved: u32,
 }
 
 pub enum yk_context {}

@@ -142,7 +142,7 @@ def test_many_tiles_per_block_is_deterministic(yk):
         outs.append((out, st.rays, st.shadow_rays, st.batches))
         sc.close()
         c.close()
-    assert [o[3] for o in outs] == [1, 8, 2, 3]  # one batch; eight; two halves on two streams; three alternating
+    assert [o[3] for o in outs] == [1, 8, 1, 3]  # one batch; eight; one batch again (a job that fits is not split); three alternating on two streams
     for o in outs[1:]:
         assert o[1] == outs[0][1] and o[2] == outs[0][2]
         assert np.array_equal(_bits(o[0]), _bits(outs[0][0]))
@@ -200,3 +200,29 @@ def test_traversal_layout_options_do_not_change_the_image(yk, oracle, option, va
             assert np.array_equal(_bits(got), _bits(want))
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("keep", ["none", "area", "delta"])
+def test_light_subsets(ctx, yk, oracle, keep):
+    """No lights at all (background only), only the area light, only the point lights: the
+    shadow-ray queues (area / delta) and their kernels each run alone or not at all."""
+    import copy
+
+    sd = copy.copy(scenes.by_name("city-tiny"))
+    kinds = [l["kind"] for l in sd.lights]
+    assert "rect" in kinds and "point" in kinds
+    if keep == "none":
+        sd.lights = []
+        sd.tri_area_light = np.full_like(sd.tri_area_light, -1)
+    elif keep == "area":
+        sd.lights = [l for l in sd.lights if l["kind"] == "rect"]
+    else:
+        sd.lights = [l for l in sd.lights if l["kind"] != "rect"]
+        sd.tri_area_light = np.full_like(sd.tri_area_light, -1)
+    sd.background = (0.3, 0.35, 0.4)
+    sampler = yk.SamplerType.Stratified((2, 2), True, SEED)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=5))
+    got, stats, want, rays = _render_both(ctx, yk, oracle, sd, (96, 54), sampler, integ)
+    assert stats.rays == rays
+    assert np.array_equal(_bits(got), _bits(want))
+    assert got.mean() > 0.01

@@ -59,6 +59,8 @@ class RenderStats(C.Structure):
         ("seconds_shade", C.c_double),
         ("trace_launches", C.c_uint32),
         ("batches", C.c_uint32),
+        ("shadow_launches", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

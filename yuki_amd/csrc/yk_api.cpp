@@ -856,7 +856,8 @@ struct KernelTimer {
 
 // one batch of `n` paths already generated into buffer 0; runs the bounce loop
 static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* scene, const RenderParams& prm, const uint32_t* pixel_xy,
-                        const uint32_t* sample_index_tab, float4* sample_buf, KernelTimer& kt, unsigned long long* counters, bool coherent) {
+                        const uint32_t* sample_index_tab, float4* sample_buf, KernelTimer& kt, unsigned long long* counters, bool coherent,
+                        uint32_t* n_shadow_launches = nullptr) {
     unsigned* ctrl = ws.ctrl.as<unsigned>();
     const DevScene& ds = scene->dev;
     const unsigned tg = trace_grid(ctx);
@@ -910,11 +911,13 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         } else {
             launch_trace_any(sb, tg, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), ctrl + YK_CTRL_SHQ,
                              ctrl + YK_CTRL_HEADS + 3 * b + 1, ws.vis.as<unsigned char>(), any_spill, tg * trace_block_size(), ctrl, counters + 1);
+            if (split && n_shadow_launches) ++*n_shadow_launches;
             if (split)  // rays converging on a point / spot / distant light: wave packets
                 launch_trace_any_packet(sb, pg, ds, ws.shO2.as<float4>(), ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), ctrl + YK_CTRL_SHQ2,
                                         ctrl + YK_CTRL_HEADS + 3 * b + 2, ws.vis.as<unsigned char>(), counters + 1);
         }
         kt.end(e, 1, sb);
+        if (n_shadow_launches) ++*n_shadow_launches;
         launch_accumulate(sb, sg, prm, pc, ws.pend.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ds.n_lights, sample_buf, ctrl, cur);
         if (overlap) (void)hipEventRecord(ws.ev_acc, sb);
         if (kt.on && std::getenv("YK_DEBUG_BOUNCES")) {  // per-bounce breakdown (synchronises; diagnostics only)
@@ -1012,7 +1015,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         HIP_TRY(ctx, hipEventCreate(&ev1));
         HIP_TRY(ctx, hipEventRecord(ev0, st));
     }
-    uint32_t n_batches = 0, n_trace = 0;
+    uint32_t n_batches = 0, n_trace = 0, n_shadow = 0;
     float* out = reinterpret_cast<float*>(d_out_rgb);
 
     size_t t_begin = 0;
@@ -1064,7 +1067,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
             launch_raygen(bs, cam, prm, pixel_xy, pixel_sample, w0, n, path_buffers(ws, 0), sample_buf, ctrl);
             ++n_batches;
             if (is_path) {
-                run_bounces(ctx, ws, bs, scene, prm, pixel_xy, pixel_sample, sample_buf, kt, counters, true);
+                run_bounces(ctx, ws, bs, scene, prm, pixel_xy, pixel_sample, sample_buf, kt, counters, true, &n_shadow);
                 n_trace += prm.max_depth;
             } else {
                 PathBuffers pc = path_buffers(ws, 0);
@@ -1110,6 +1113,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         stats->seconds_shadow = kt.total(1);
         stats->seconds_shade = kt.total(2);
         stats->trace_launches = n_trace;
+        stats->shadow_launches = n_shadow;
         stats->batches = n_batches;
         (void)hipEventDestroy(ev0);
         (void)hipEventDestroy(ev1);
