@@ -86,11 +86,12 @@ struct PktStack {
 };
 
 // rays claimed per atomic: up to YK_PKT_CHUNK packets, fewer when the queue is short so that
-// every resident wave gets work
+// every resident wave makes about eight claims (two claims per wave left the last waves of a
+// 16 M-ray launch with 50 % more work than the rest)
 #define YK_PKT_CHUNK 16
 __device__ __forceinline__ unsigned pkt_claim_size(unsigned n) {
     const unsigned waves = gridDim.x * (blockDim.x / YK_WAVE);
-    unsigned packets = n / (waves * YK_WAVE);
+    unsigned packets = n / (waves * YK_WAVE * 8u);
     packets = packets < 1u ? 1u : (packets > (unsigned)YK_PKT_CHUNK ? (unsigned)YK_PKT_CHUNK : packets);
     return packets * YK_WAVE;
 }
