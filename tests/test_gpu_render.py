@@ -226,3 +226,52 @@ def test_light_subsets(ctx, yk, oracle, keep):
     assert stats.rays == rays
     assert np.array_equal(_bits(got), _bits(want))
     assert got.mean() > 0.01
+
+
+def test_render_from_worker_threads(ctx, yk):
+    """The reference calls Integrator::render from num_cpus-1 tile workers at once
+    (render_manager.rs:78-97); calls on one context are serialised inside the library and give
+    the same pixels as one batched call."""
+    import threading
+
+    sd = scenes.by_name("city-tiny")
+    sc = yk.Scene(ctx, sd)
+    fs = yk.FilmSettings(res=(128, 72))
+    cam = yk.Camera(sd.camera, fs)
+    tiles = yk.film_tiles(fs)
+    smp = yk.SamplerType.Uniform(4, SEED)
+    it = yk.IntegratorType.instantiate(ctx, yk.IntegratorType.Path(yk.PathParams(max_depth=5)))
+    ref, ref_stats = it.render_tiles(sc, cam, smp, tiles)
+    offs = np.concatenate([[0], np.cumsum((tiles["x1"].astype(int) - tiles["x0"]) * (tiles["y1"].astype(int) - tiles["y0"]))])
+    out = np.zeros_like(ref)
+    errs, rays = [], []
+
+    def worker(k):
+        try:
+            for t in range(k, len(tiles), 6):
+                px, n = it.render(sc, cam, smp, yk.FilmTile(tuple(int(v) for v in tiles[t])))
+                out[offs[t] : offs[t + 1]] = px
+                rays.append(n)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs
+    assert sum(rays) == ref_stats.rays
+    assert np.array_equal(_bits(out), _bits(ref))
+
+
+def test_render_one_tile_accumulating(ctx, yk, oracle):
+    """Integrator::render(accumulating=true) through the one-tile entry point."""
+    sd = scenes.by_name("city-tiny")
+    fs = yk.FilmSettings(res=(64, 48), accumulate=True)
+    cam = yk.Camera(sd.camera, fs)
+    smp = yk.SamplerType.Stratified((2, 2), True, SEED)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=4))
+    it = yk.IntegratorType.instantiate(ctx, integ)
+    tile = yk.FilmTile((16, 16, 32, 32), sample=3)
+    got, rays = it.render(yk.Scene(ctx, sd), cam, smp, tile, accumulating=True)
+    want, wrays = oracle.OracleScene(sd).render_tiles_accumulating(cam.matrices, smp, integ, np.array([tile.bb], dtype=abi.TILE_DTYPE), [3])
+    assert rays == wrays and np.array_equal(_bits(got), _bits(want))

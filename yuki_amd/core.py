@@ -269,12 +269,15 @@ class Integrator:
 
     def render(self, scene, camera, sampler, tile, accumulating=False):
         """One tile; returns (tile_pixels[h*w,3], ray_count) — integrators/mod.rs:120-185."""
-        if accumulating:
-            raise YukiError(5, "accumulating film mode is not implemented (SURVEY §8 quirk 17)")
         t = tile.as_struct() if isinstance(tile, FilmTile) else abi.Tile(*[int(v) for v in tile])
         w, h = t.x1 - t.x0, t.y1 - t.y0
         if w <= 0 or h <= 0:
             raise YukiError(1, "Bounds2 with a dimension <= 0")
+        if accumulating:  # one sample with global index tile.sample, raw value (integrators/mod.rs:146-161)
+            sample = tile.sample if isinstance(tile, FilmTile) else 0
+            tiles = np.array([(t.x0, t.y0, t.x1, t.y1)], dtype=abi.TILE_DTYPE)
+            px, stats = self.render_tiles_accumulating(scene, camera, sampler, tiles, [sample])
+            return px, stats.rays
         px = np.zeros((w * h, 3), dtype=np.float32)
         rays = C.c_uint64(0)
         check(lib().yk_render_tile(self.ctx.h, scene.h, C.byref(camera.matrices), C.byref(sampler), C.byref(self.desc), C.byref(t), _p(px), C.byref(rays)), self.ctx.h)

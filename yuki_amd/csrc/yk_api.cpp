@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -72,6 +73,9 @@ struct yk_context {
     } ws[2];
     DevBuf sample_buf, pixel_xy, tiles, tile_off, counters, stats4, hit4, scratch[8];
     std::vector<hipEvent_t> ev_pool;
+    // every entry point that touches the context's buffers or streams holds this: calls on one
+    // context from several host threads (the reference's tile workers) are serialised
+    std::recursive_mutex mu;
 };
 
 typedef yk_context::WorkSet WorkSet;
@@ -93,6 +97,7 @@ static yk_status fail(yk_context* ctx, yk_status st, const std::string& msg) {
     return st;
 }
 
+#define YK_LOCK(ctx) std::lock_guard<std::recursive_mutex> yk_lock_((ctx)->mu)
 #define HIP_TRY(ctx, expr)                                                                                           \
     do {                                                                                                             \
         hipError_t _e = (expr);                                                                                      \
@@ -200,6 +205,7 @@ yk_status yk_last_error(const yk_context* ctx, char* buf, size_t cap) {
 
 yk_status yk_context_set_option(yk_context* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
     std::string k(key);
     if (k == "batch_paths") {
         if (value < 64 || value > ((int64_t)1 << 30)) return YK_ERR_INVALID_ARGUMENT;
@@ -384,6 +390,8 @@ static DevLight make_light(const yk_light_desc& l) {
 }
 
 yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** out) {
+    std::unique_lock<std::recursive_mutex> yk_lock_;
+    if (ctx) yk_lock_ = std::unique_lock<std::recursive_mutex>(ctx->mu);
     if (!d || !out) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null scene description");
     *out = nullptr;
     if ((uint64_t)d->n_triangles + d->n_spheres == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "empty scene");
@@ -948,6 +956,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
                                    const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
                                    void* d_out_rgb, void* stream, yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
     if (!scene || !camera || !tiles || n_tiles == 0 || !d_out_rgb) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     if (!scene->on_device || scene->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context");
     RenderParams prm;
@@ -1138,6 +1147,7 @@ yk_status yk_render_tiles_accumulating_device(yk_context* ctx, const yk_scene* s
                                               const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
                                               void* d_out_rgb, void* stream, yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
     if (!tile_samples) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null tile_samples");
     return render_tiles_impl(ctx, scene, camera, sampler, integrator, tiles, tile_samples, n_tiles, d_out_rgb, stream, stats, cancel, user);
 }
@@ -1146,6 +1156,7 @@ yk_status yk_render_tiles_accumulating(yk_context* ctx, const yk_scene* scene, c
                                        const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
                                        float* out_rgb, yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
     if (!tile_samples) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null tile_samples");
     return render_tiles_host(ctx, scene, camera, sampler, integrator, tiles, tile_samples, n_tiles, out_rgb, stats, cancel, user);
 }
@@ -1162,6 +1173,7 @@ static yk_status render_tiles_host(yk_context* ctx, const yk_scene* scene, const
                                    const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
                                    float* out_rgb, yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
     if (!tiles || n_tiles == 0 || !out_rgb) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     uint64_t total_px = 0;
     for (size_t t = 0; t < n_tiles; ++t) {
@@ -1210,6 +1222,7 @@ yk_status yk_film_accumulate_tiles_device(yk_context* ctx, const yk_tile* tiles,
 static yk_status film_tiles_device(yk_context* ctx, const yk_tile* tiles, size_t n_tiles, const void* d_tile_rgb, uint16_t res_x, uint16_t res_y,
                                    void* d_film_rgb, void* stream, int accumulate) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
     if (!tiles || !d_tile_rgb || !d_film_rgb || n_tiles == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
@@ -1242,6 +1255,7 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
                 const float* ray_o, const float* ray_d, const uint16_t* pixel_xy, const uint32_t* sample_index, uint32_t dimension, float* out_li,
                 uint32_t* out_ray_counts) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
     if (!scene || !ray_o || !ray_d || !pixel_xy || !sample_index || !out_li || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     if (!scene->on_device || scene->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context");
     if (n > ((size_t)1 << 28)) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many rays");
@@ -1293,6 +1307,7 @@ yk_status yk_trace_closest(yk_context* ctx, const yk_scene* scene, size_t n, con
                            int32_t* out_shape, float* out_t, float* out_bary, uint32_t* out_node_tests, uint32_t* out_node_hits,
                            uint32_t* out_shape_tests) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
     if (!scene || !ray_o || !ray_d || !out_shape || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     if (!scene->on_device || scene->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context");
     if (n > 0xFFFFFF00ull) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many rays");
@@ -1353,6 +1368,7 @@ yk_status yk_trace_closest(yk_context* ctx, const yk_scene* scene, size_t n, con
 yk_status yk_trace_any(yk_context* ctx, const yk_scene* scene, size_t n, const float* ray_o, const float* ray_d, const float* t_max,
                        const int32_t* area_light, uint8_t* out_hit) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
     if (!scene || !ray_o || !ray_d || !t_max || !out_hit || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     if (!scene->on_device || scene->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context");
     if (n > 0xFFFFFF00ull) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many rays");
@@ -1387,6 +1403,7 @@ yk_status yk_trace_any(yk_context* ctx, const yk_scene* scene, size_t n, const f
 yk_status yk_sampler_sequence(yk_context* ctx, const yk_sampler_desc* sampler, uint16_t px, uint16_t py, uint32_t sample_index, const uint8_t* dims,
                               size_t n_draws, float* out) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
     if (!sampler || !dims || !out || n_draws == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     RenderParams prm;
     yk_integrator_desc dummy = {YK_INTEGRATOR_PATH, 1, 0, 0.0f};
@@ -1407,6 +1424,7 @@ yk_status yk_sampler_sequence(yk_context* ctx, const yk_sampler_desc* sampler, u
 yk_status yk_camera_rays(yk_context* ctx, const yk_camera* camera, const yk_sampler_desc* sampler, const yk_tile* tile, uint32_t sample_index,
                          float* out_o, float* out_d) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
     if (!camera || !sampler || !tile || !out_o || !out_d) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     if (tile->x0 >= tile->x1 || tile->y0 >= tile->y1) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "Bounds2 with a dimension <= 0");
     RenderParams prm;
@@ -1452,6 +1470,7 @@ yk_status yk_camera_rays(yk_context* ctx, const yk_camera* camera, const yk_samp
 
 yk_status yk_device_math(yk_context* ctx, int fn, size_t n, const float* a, const float* b, float* out) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
     if (!a || !out || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
@@ -1470,6 +1489,7 @@ yk_status yk_device_math(yk_context* ctx, int fn, size_t n, const float* a, cons
 static yk_status bsdf_common(yk_context* ctx, const yk_material_desc* material, size_t n, const float* n_geom, const float* n_shading,
                              const float* dpdu, const float* wo, const float* x, int sample, float* out) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
     if (!material || !n_geom || !n_shading || !dpdu || !wo || !x || !out || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
