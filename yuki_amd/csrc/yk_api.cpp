@@ -1018,7 +1018,15 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
     KernelTimer kt;
     kt.ctx = ctx;
     kt.on = stats != nullptr && ctx->time_kernels != 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct EventPair {  // destroyed on every exit path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() {
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+        }
+    } frame_ev;
+    hipEvent_t& ev0 = frame_ev.a;
+    hipEvent_t& ev1 = frame_ev.b;
     if (stats) {
         HIP_TRY(ctx, hipEventCreate(&ev0));
         HIP_TRY(ctx, hipEventCreate(&ev1));
@@ -1064,8 +1072,6 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
             if (cancel && cancel(user)) {
                 (void)hipStreamSynchronize(st);
                 if (n_ws == 2) (void)hipStreamSynchronize(ctx->ws[1].stream);
-                if (ev0) (void)hipEventDestroy(ev0);
-                if (ev1) (void)hipEventDestroy(ev1);
                 return fail(ctx, YK_ERR_CANCELLED, "cancelled by early_termination_predicate");
             }
             WorkSet& ws = ctx->ws[which];
@@ -1124,8 +1130,6 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         stats->trace_launches = n_trace;
         stats->shadow_launches = n_shadow;
         stats->batches = n_batches;
-        (void)hipEventDestroy(ev0);
-        (void)hipEventDestroy(ev1);
         if (host_ctrl[YK_CTRL_ERR] & 1u) return fail(ctx, YK_ERR_STACK_OVERFLOW, "BVH traversal stack exceeded 64 entries (bvh.rs:174)");
     }
     return YK_OK;

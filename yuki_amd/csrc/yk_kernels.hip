@@ -405,7 +405,17 @@ __global__ void k_resolve(const float4* sample_buf, uint32_t n_pixels, uint32_t 
     if (p >= n_pixels) return;
     RGB color = RGB{0.0f, 0.0f, 0.0f};
     const float4* s = sample_buf + (size_t)p * spp;
-    for (uint32_t k = 0; k < spp; ++k) {
+    // the sum keeps the reference's sample order (integrators/mod.rs:172); the loads of a group
+    // of eight are issued together so the serial adds do not wait for one load each
+    uint32_t k = 0;
+    for (; k + 8 <= spp; k += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = s[k + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) color = color + RGB{v[j].x, v[j].y, v[j].z};
+    }
+    for (; k < spp; ++k) {
         float4 v = s[k];
         color = color + RGB{v.x, v.y, v.z};
     }
