@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--async-steps", action="store_true", help="N=1: enqueue the timed steps without host synchronisation, as N>1 always does")
     ap.add_argument("--cpu-sample-tiles", type=int, default=384)
     args = ap.parse_args()
 
@@ -143,19 +144,24 @@ def main():
     film = torch.zeros(wl["res"][1] * wl["res"][0] * 3, dtype=torch.float32, device=dev) if rank == 0 else None
     gathered = [torch.zeros_like(slab) for _ in range(world)] if (rank == 0 and world > 1) else None
 
-    def step():
-        st = it.render_tiles_device(scene, cam, sampler, my_tiles, slab.data_ptr(), want_stats=True)  # syncs the render stream
+    # Prepared tile lists: the pixel tables live on the device, so a step needs no upload.
+    my_list = yk.TileList(ctx, my_tiles)
+    rank_lists = [yk.TileList(ctx, ydist.shard_tiles(tiles, r, world)) for r in range(world)] if (rank == 0 and world > 1) else None
+    # N > 1 (or --async-steps): every launch of a step — render, RCCL gather, film scatter — is
+    # enqueued on torch's current stream and nothing waits on the host inside the timed region;
+    # ray counts are taken from one synchronous step beforehand (every step renders the same frame).
+    async_steps = world > 1 or args.async_steps
+
+    def step(want_stats=True):
+        cs = torch.cuda.current_stream().cuda_stream if async_steps else None
+        st = it.render_tile_list_device(scene, cam, sampler, my_list, slab.data_ptr(), stream=cs, want_stats=want_stats)
         if world > 1:
-            dist.gather(slab, gathered, dst=0)  # RCCL, enqueued on torch's stream
+            dist.gather(slab, gathered, dst=0)  # RCCL, same stream
             if rank == 0:
-                torch.cuda.current_stream().synchronize()  # the scatter below runs on the library's own stream
                 for r in range(world):
-                    tr = ydist.shard_tiles(tiles, r, world)
-                    yk.check(yk.lib().yk_film_update_tiles_device(ctx.h, tr.ctypes.data_as(ctypes.c_void_p), len(tr), ctypes.c_void_p(gathered[r].data_ptr()),
-                                                                   wl["res"][0], wl["res"][1], ctypes.c_void_p(film.data_ptr()), None), ctx.h)
+                    rank_lists[r].update_film_device(gathered[r].data_ptr(), wl["res"], film.data_ptr(), stream=cs)
         else:
-            yk.check(yk.lib().yk_film_update_tiles_device(ctx.h, my_tiles.ctypes.data_as(ctypes.c_void_p), len(my_tiles), ctypes.c_void_p(slab.data_ptr()),
-                                                           wl["res"][0], wl["res"][1], ctypes.c_void_p(film.data_ptr()), None), ctx.h)
+            my_list.update_film_device(slab.data_ptr(), wl["res"], film.data_ptr(), stream=cs)
         return st
 
     def sync():
@@ -166,13 +172,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    probe = step() if async_steps else None  # untimed: per-step ray counts and kernel timings for the asynchronous mode
     sync()
     t0 = time.perf_counter()
     rays = shadow = 0
     t_trace = t_shadow = t_shade = t_dev = 0.0
     launches = shadow_launches = 0
     for _ in range(args.steps):
-        st = step()
+        st = step(want_stats=not async_steps) or probe
         rays += st.rays
         shadow += st.shadow_rays
         t_trace += st.seconds_trace
@@ -259,7 +266,9 @@ def main():
             "extra": {"rays_per_step": rays_all // args.steps, "shadow_rays_per_step": shadow_all // args.steps,
                       "shadow_Mray_per_s": shadow_all / elapsed * 1e-6, "rank0_device_s_per_step": t_dev / args.steps,
                       "rank0_trace_s": t_trace / args.steps, "rank0_shadow_s": t_shadow / args.steps, "rank0_shade_s": t_shade / args.steps,
-                      "film_mean_rgb": film_mean, "bvh_build_s": info.build_seconds, "scene_upload_s": info.upload_seconds},
+                      "film_mean_rgb": film_mean, "bvh_build_s": info.build_seconds, "scene_upload_s": info.upload_seconds,
+                      "steps_mode": "asynchronous (no host sync inside the timed region; per-kernel times and ray counts from one untimed probe step)" if async_steps
+                      else "synchronous (per-kernel HIP-event times read after every step of the timed region)"},
         }
         print(json.dumps(out), flush=True)
     scene.close()

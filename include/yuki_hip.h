@@ -278,6 +278,21 @@ yk_status yk_film_accumulate_tiles(const yk_tile* tiles, size_t n_tiles, const f
                                    uint32_t* tile_sample_counts);
 yk_status yk_film_accumulate_tiles_device(yk_context* ctx, const yk_tile* tiles, size_t n_tiles, const void* d_tile_rgb, uint16_t res_x,
                                           uint16_t res_y, void* d_film_rgb, void* stream);
+/* A tile list prepared once and reused every frame — what a GPU worker does with the film's
+ * tile queue (render_manager.rs:125-143).  The list keeps a device-resident pixel table, so
+ * yk_render_tile_list_device (with stats == NULL) and yk_film_update_tile_list_device enqueue
+ * their work on `stream` and return without any host synchronisation; results are identical
+ * to the yk_tile-array entry points.  tile_samples != NULL makes it an accumulating-film list
+ * (FilmTile.sample per tile). */
+typedef struct yk_tile_list yk_tile_list;
+yk_status yk_tile_list_create(yk_context* ctx, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles, yk_tile_list** out);
+void yk_tile_list_destroy(yk_tile_list* list);
+yk_status yk_render_tile_list_device(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                     const yk_integrator_desc* integrator, const yk_tile_list* list, void* d_out_rgb, void* stream,
+                                     yk_render_stats* stats, yk_cancel_fn cancel, void* user);
+yk_status yk_film_update_tile_list_device(yk_context* ctx, const yk_tile_list* list, const void* d_tile_rgb, uint16_t res_x, uint16_t res_y,
+                                          void* d_film_rgb, void* stream, int accumulate);
+
 /* Film output (app/util.rs:90-111 write_exr -> exr::prelude::write_rgb_file): an OpenEXR 2
  * scan-line file with three FLOAT channels B, G, R, uncompressed, increasing Y — readable by
  * the tools the reference targets (readme.md:46-47); and a little-endian PFM ("PF") writer.

@@ -162,3 +162,40 @@ def test_film_accumulate_device(ctx, yk):
         torch.cuda.synchronize()
         yk.check(yk.lib().yk_film_accumulate_tiles_device(ctx.h, tiles.ctypes.data, len(tiles), t.data_ptr(), 50, 30, film_d.data_ptr(), None), ctx.h)
     assert film_d.cpu().numpy().tobytes() == film_h.tobytes()
+
+
+@pytest.mark.gpu
+def test_prepared_tile_list_matches_the_array_entry_points(ctx, yk):
+    """yk_tile_list: render + film update from a device-resident tile list, enqueued on a caller
+    stream without host synchronisation, equals yk_render_tiles + yk_film_update_tiles."""
+    import torch
+
+    sd = scenes.by_name("city-tiny")
+    fs = yk.FilmSettings(res=(100, 60), tile_dim=16)
+    cam = yk.Camera(sd.camera, fs)
+    tiles = yk.film_tiles(fs)[::2]  # a shard: every other tile
+    smp = yk.SamplerType.Stratified((2, 2), True, 0x73B9642E74AC471C)
+    it = yk.IntegratorType.instantiate(ctx, yk.IntegratorType.Path(yk.PathParams(max_depth=5)))
+    sc = yk.Scene(ctx, sd)
+    want, _ = it.render_tiles(sc, cam, smp, tiles)
+    want_film = yk.update_tiles(tiles, want, fs.res)
+    tl = yk.TileList(ctx, tiles)
+    assert tl.n_pixels == want.shape[0]
+    stream = torch.cuda.Stream()
+    slab = torch.zeros(tl.n_pixels * 3, dtype=torch.float32, device="cuda:0")
+    film = torch.zeros(60 * 100 * 3, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    for _ in range(3):  # back-to-back frames, nothing waits on the host in between
+        it.render_tile_list_device(sc, cam, smp, tl, slab.data_ptr(), stream=stream.cuda_stream)
+        tl.update_film_device(slab.data_ptr(), fs.res, film.data_ptr(), stream=stream.cuda_stream)
+    stream.synchronize()
+    assert slab.cpu().numpy().tobytes() == want.tobytes()
+    assert film.cpu().numpy().tobytes() == want_film.tobytes()
+    st = it.render_tile_list_device(sc, cam, smp, tl, slab.data_ptr(), want_stats=True)
+    assert st.samples == tl.n_pixels * 4 and st.rays > 0
+    # accumulating list: one sample per pixel with the list's per-tile sample index
+    acc = yk.TileList(ctx, tiles, np.full(len(tiles), 2, dtype=np.uint16))
+    it.render_tile_list_device(sc, cam, smp, acc, slab.data_ptr(), want_stats=True)
+    got_acc = slab.cpu().numpy().reshape(-1, 3)
+    want_acc, _ = it.render_tiles_accumulating(sc, cam, smp, tiles, np.full(len(tiles), 2, dtype=np.uint16))
+    assert got_acc.tobytes() == want_acc.tobytes()

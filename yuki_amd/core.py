@@ -92,6 +92,34 @@ def write_pfm(path, film):
     check(lib().yk_write_pfm(str(path).encode(), film.shape[1], film.shape[0], _p(film)))
 
 
+class TileList:
+    """A tile list prepared once on the device (yk_tile_list): the GPU worker's tile queue."""
+
+    def __init__(self, ctx, tiles, tile_samples=None):
+        self.ctx = ctx
+        self.tiles = np.ascontiguousarray(tiles, dtype=abi.TILE_DTYPE)
+        ts = None if tile_samples is None else np.ascontiguousarray(tile_samples, dtype=np.uint16)
+        h = C.c_void_p()
+        check(lib().yk_tile_list_create(ctx.h, _p(self.tiles), _p(ts), len(self.tiles), C.byref(h)), ctx.h)
+        self.h = h
+        self.n_pixels = int(((self.tiles["x1"].astype(np.int64) - self.tiles["x0"]) * (self.tiles["y1"].astype(np.int64) - self.tiles["y0"])).sum())
+
+    def update_film_device(self, d_tile_rgb_ptr, res, d_film_ptr, stream=None, accumulate=False):
+        """Film::update_tile for the whole list, device to device, enqueued on `stream`."""
+        check(lib().yk_film_update_tile_list_device(self.ctx.h, self.h, C.c_void_p(d_tile_rgb_ptr), res[0], res[1], C.c_void_p(d_film_ptr), C.c_void_p(stream) if stream else None, 1 if accumulate else 0), self.ctx.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().yk_tile_list_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # --------------------------------------------------------------------------- camera
 class FoV:
     X, Y = abi.FOV_X, abi.FOV_Y
@@ -323,6 +351,16 @@ class Integrator:
             self.ctx.h,
         )
         return stats
+
+    def render_tile_list_device(self, scene, camera, sampler, tile_list, d_out_ptr, stream=None, want_stats=False):
+        """Render a prepared TileList into HBM at `d_out_ptr`; with want_stats=False the call only
+        enqueues work on `stream` (no host synchronisation)."""
+        stats = RenderStats()
+        check(
+            lib().yk_render_tile_list_device(self.ctx.h, scene.h, C.byref(camera.matrices), C.byref(sampler), C.byref(self.desc), tile_list.h, C.c_void_p(d_out_ptr), C.c_void_p(stream) if stream else None, C.byref(stats) if want_stats else None, None, None),
+            self.ctx.h,
+        )
+        return stats if want_stats else None
 
     def li(self, scene, sampler, ray_o, ray_d, pixel_xy, sample_index, dimension=2):
         """Integrator::li for caller-supplied rays (integrators/mod.rs:94-101)."""

@@ -92,6 +92,18 @@ struct yk_scene {
     bool on_device = false;
 };
 
+// A tile list prepared once and reused every frame (the GPU worker renders the same tiles
+// over and over): host copy + the device pixel table, so that rendering and the film update
+// need no upload and no host synchronisation.
+struct yk_tile_list {
+    yk_context* ctx = nullptr;
+    int device = -1;
+    std::vector<yk_tile> tiles;
+    std::vector<uint16_t> samples;  // empty: plain film
+    std::vector<uint32_t> off;      // n_tiles + 1 pixel offsets
+    DevBuf pixel_xy, pixel_sample;
+};
+
 static yk_status fail(yk_context* ctx, yk_status st, const std::string& msg) {
     if (ctx) ctx->last_error = msg;
     return st;
@@ -954,9 +966,16 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
 // 146-161): one sample per pixel with global index tile_samples[t], raw value stored.
 static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
                                    const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
-                                   void* d_out_rgb, void* stream, yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
+                                   void* d_out_rgb, void* stream, yk_render_stats* stats, yk_cancel_fn cancel, void* user,
+                                   const yk_tile_list* prepared = nullptr) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
+    if (prepared) {
+        if (prepared->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "tile list was not created on this context");
+        tiles = prepared->tiles.data();
+        tile_samples = prepared->samples.empty() ? nullptr : prepared->samples.data();
+        n_tiles = prepared->tiles.size();
+    }
     if (!scene || !camera || !tiles || n_tiles == 0 || !d_out_rgb) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     if (!scene->on_device || scene->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context");
     RenderParams prm;
@@ -1041,17 +1060,22 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         while (t_end < n_tiles && (uint64_t)(off[t_end + 1] - off[t_begin]) <= max_px_chunk) ++t_end;
         if (t_end == t_begin) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "a single tile exceeds sample_buf_cap");
         const uint32_t px0 = off[t_begin], npx = off[t_end] - off[t_begin];
+        HIP_TRY(ctx, ctx->sample_buf.ensure((size_t)npx * spp * 16));
+        float4* sample_buf = ctx->sample_buf.as<float4>();
+        uint32_t* pixel_xy = nullptr;
+        uint32_t* pixel_sample = nullptr;
+        const uint16_t* d_tile_sample = nullptr;
+        if (prepared) {  // the pixel table of the whole list is already on the device
+            pixel_xy = prepared->pixel_xy.as<uint32_t>() + px0;
+            if (accumulating) pixel_sample = prepared->pixel_sample.as<uint32_t>() + px0;
+        } else {
         std::vector<uint32_t> loc(t_end - t_begin + 1);
         for (size_t t = t_begin; t <= t_end; ++t) loc[t - t_begin] = off[t] - px0;
         HIP_TRY(ctx, hipMemcpyAsync(ctx->tiles.p, tiles + t_begin, (t_end - t_begin) * sizeof(yk_tile), hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->tile_off.p, loc.data(), loc.size() * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));  // `loc` is a stack-lifetime staging buffer
         HIP_TRY(ctx, ctx->pixel_xy.ensure((size_t)npx * 4));
-        HIP_TRY(ctx, ctx->sample_buf.ensure((size_t)npx * spp * 16));
-        uint32_t* pixel_xy = ctx->pixel_xy.as<uint32_t>();
-        float4* sample_buf = ctx->sample_buf.as<float4>();
-        uint32_t* pixel_sample = nullptr;
-        const uint16_t* d_tile_sample = nullptr;
+        pixel_xy = ctx->pixel_xy.as<uint32_t>();
         if (accumulating) {
             HIP_TRY(ctx, ctx->scratch[4].ensure((t_end - t_begin) * 2));
             HIP_TRY(ctx, ctx->scratch[5].ensure((size_t)npx * 4));
@@ -1060,6 +1084,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
             pixel_sample = ctx->scratch[5].as<uint32_t>();
         }
         launch_pixel_table(st, ctx->tiles.as<yk_tile>(), ctx->tile_off.as<uint32_t>(), (uint32_t)(t_end - t_begin), npx, pixel_xy, d_tile_sample, pixel_sample);
+        }
         // the second stream starts after the pixel table exists
         if (n_ws == 2) {
             HIP_TRY(ctx, hipEventRecord(ctx->ws[0].done, st));
@@ -1163,6 +1188,97 @@ yk_status yk_render_tiles_accumulating(yk_context* ctx, const yk_scene* scene, c
     YK_LOCK(ctx);
     if (!tile_samples) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null tile_samples");
     return render_tiles_host(ctx, scene, camera, sampler, integrator, tiles, tile_samples, n_tiles, out_rgb, stats, cancel, user);
+}
+
+yk_status yk_tile_list_create(yk_context* ctx, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles, yk_tile_list** out) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
+    if (!tiles || !out || n_tiles == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    yk_tile_list* l = new yk_tile_list();
+    l->ctx = ctx;
+    l->device = ctx->device;
+    l->tiles.assign(tiles, tiles + n_tiles);
+    if (tile_samples) l->samples.assign(tile_samples, tile_samples + n_tiles);
+    l->off.assign(n_tiles + 1, 0);
+    uint64_t total = 0;
+    for (size_t t = 0; t < n_tiles; ++t) {
+        if (tiles[t].x0 >= tiles[t].x1 || tiles[t].y0 >= tiles[t].y1) {
+            delete l;
+            return fail(ctx, YK_ERR_INVALID_ARGUMENT, "Bounds2 with a dimension <= 0");
+        }
+        total += (uint64_t)(tiles[t].x1 - tiles[t].x0) * (uint64_t)(tiles[t].y1 - tiles[t].y0);
+        if (total > 0xFFFFFFFFull) {
+            delete l;
+            return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many pixels in one list");
+        }
+        l->off[t + 1] = (uint32_t)total;
+    }
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    yk_status rc = YK_OK;
+    auto tryhip = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == YK_OK) rc = fail(ctx, e == hipErrorOutOfMemory ? YK_ERR_OUT_OF_MEMORY : YK_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    };
+    tryhip(ctx->tiles.ensure(n_tiles * sizeof(yk_tile)), "tiles");
+    tryhip(ctx->tile_off.ensure((n_tiles + 1) * 4), "tile offsets");
+    tryhip(l->pixel_xy.ensure((size_t)total * 4), "pixel table");
+    if (tile_samples) {
+        tryhip(ctx->scratch[4].ensure(n_tiles * 2), "tile samples");
+        tryhip(l->pixel_sample.ensure((size_t)total * 4), "pixel samples");
+    }
+    if (rc == YK_OK) {
+        tryhip(hipMemcpyAsync(ctx->tiles.p, tiles, n_tiles * sizeof(yk_tile), hipMemcpyHostToDevice, st), "upload tiles");
+        tryhip(hipMemcpyAsync(ctx->tile_off.p, l->off.data(), l->off.size() * 4, hipMemcpyHostToDevice, st), "upload offsets");
+        if (tile_samples) tryhip(hipMemcpyAsync(ctx->scratch[4].p, tile_samples, n_tiles * 2, hipMemcpyHostToDevice, st), "upload samples");
+    }
+    if (rc == YK_OK) {
+        launch_pixel_table(st, ctx->tiles.as<yk_tile>(), ctx->tile_off.as<uint32_t>(), (uint32_t)n_tiles, (uint32_t)total, l->pixel_xy.as<uint32_t>(),
+                           tile_samples ? ctx->scratch[4].as<uint16_t>() : nullptr, tile_samples ? l->pixel_sample.as<uint32_t>() : nullptr);
+        tryhip(hipGetLastError(), "pixel table kernel");
+        tryhip(hipStreamSynchronize(st), "sync");
+    }
+    if (rc != YK_OK) {
+        l->pixel_xy.release();
+        l->pixel_sample.release();
+        delete l;
+        return rc;
+    }
+    *out = l;
+    return YK_OK;
+}
+
+void yk_tile_list_destroy(yk_tile_list* l) {
+    if (!l) return;
+    if (l->device >= 0) (void)hipSetDevice(l->device);
+    l->pixel_xy.release();
+    l->pixel_sample.release();
+    delete l;
+}
+
+yk_status yk_render_tile_list_device(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                     const yk_integrator_desc* integrator, const yk_tile_list* list, void* d_out_rgb, void* stream,
+                                     yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!list) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null tile list");
+    return render_tiles_impl(ctx, scene, camera, sampler, integrator, list->tiles.data(), nullptr, list->tiles.size(), d_out_rgb, stream, stats, cancel,
+                             user, list);
+}
+
+yk_status yk_film_update_tile_list_device(yk_context* ctx, const yk_tile_list* list, const void* d_tile_rgb, uint16_t res_x, uint16_t res_y,
+                                          void* d_film_rgb, void* stream, int accumulate) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
+    if (!list || !d_tile_rgb || !d_film_rgb) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
+    if (list->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "tile list was not created on this context");
+    for (const yk_tile& t : list->tiles)
+        if (t.x1 > res_x || t.y1 > res_y) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "update_tile: Tile doesn't fit film");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    launch_film_scatter(st, list->pixel_xy.as<uint32_t>(), list->off.back(), reinterpret_cast<const float*>(d_tile_rgb), res_x,
+                        reinterpret_cast<float*>(d_film_rgb), accumulate ? 1 : 0);
+    HIP_TRY(ctx, hipGetLastError());
+    return YK_OK;  // asynchronous: ordered on `stream`
 }
 
 yk_status yk_render_tiles(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
