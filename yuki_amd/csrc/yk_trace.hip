@@ -21,13 +21,13 @@
 #define TRACE_BLOCK 256
 #endif
 #ifndef TRACE_LDS
-#define TRACE_LDS 10  // stack entries per lane kept in LDS
+#define TRACE_LDS 8  // stack entries per lane kept in LDS
 #endif
 #ifndef TRACE_TOP
 #define TRACE_TOP 95  // interior nodes of the first tree levels kept in LDS (<= YK_TOP_MAX)
 #endif
 #ifndef TRACE_MIN_WAVES
-#define TRACE_MIN_WAVES 6  // waves per SIMD the register allocator must leave room for
+#define TRACE_MIN_WAVES 7  // waves per SIMD the register allocator must leave room for
 #endif
 
 namespace yk {
