@@ -87,7 +87,7 @@ struct yk_scene {
     uint32_t n_triangles = 0, n_spheres = 0, n_lights = 0, n_delta_lights = 0;
     yk_scene_info info;
     // device
-    DevBuf nodes, nodes4, top_nodes, tris, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights, spheres, texels, tex_info;
+    DevBuf nodes, nodes4, top_nodes, tris, prim_shade, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights, spheres, texels, tex_info;
     DevScene dev;
     bool on_device = false;
 };
@@ -422,6 +422,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
     for (uint32_t m = 0; m < d->n_materials; ++m)
         if ((d->materials[m].flags & YK_MAT_FLAG_TEXTURED_A) && d->materials[m].kind == YK_MAT_MATTE && d->materials[m].a_texture >= d->n_textures)
             return fail(ctx, YK_ERR_INVALID_ARGUMENT, "material texture index out of range");
+    if (d->n_materials >= (1u << 29)) return fail(ctx, YK_ERR_UNSUPPORTED, "more than 2^29 materials");
     for (uint32_t t = 0; t < d->n_textures; ++t)
         if (!d->textures || !d->textures[t].rgb || d->textures[t].width == 0 || d->textures[t].height == 0 || d->textures[t].width >= (1u << 24) ||
             d->textures[t].height >= (1u << 24))
@@ -623,6 +624,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         }
         const size_t np = s->bvh.shape_order.size();
         std::vector<float4> tris(3 * np);
+        std::vector<uint4> prim_shade(np);
         std::vector<uint8_t> last(np, 0);
         for (const yk_bvh_node& n : nodes)
             if (n.is_leaf) last[(size_t)n.a + n.count - 1] = 1;
@@ -637,6 +639,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
                 tris[3 * p + 0] = make_float4(0.0f, 0.0f, 0.0f, w0);
                 tris[3 * p + 1] = make_float4(0.0f, 0.0f, 0.0f, w1);
                 tris[3 * p + 2] = make_float4(0.0f, 0.0f, 0.0f, w2);
+                prim_shade[p] = make_uint4(0u, 0u, 0u, (uint32_t)d->spheres[src - d->n_triangles].material << 3);
                 continue;
             }
             const float* p0 = d->points + 3 * (size_t)d->indices[3 * src];
@@ -651,6 +654,9 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
             tris[3 * p + 0] = make_float4(p0[0], p0[1], p0[2], w0);
             tris[3 * p + 1] = make_float4(p1[0], p1[1], p1[2], w1);
             tris[3 * p + 2] = make_float4(p2[0], p2[1], p2[2], w2);
+            const yk_mesh_desc& md = d->meshes[d->tri_mesh ? d->tri_mesh[src] : 0];
+            const uint32_t mfl = (md.has_normals ? YK_MESH_NORMALS : 0u) | (md.has_uvs ? YK_MESH_UVS : 0u) | (md.swaps_handedness ? YK_MESH_SWAPS : 0u);
+            prim_shade[p] = make_uint4(d->indices[3 * src], d->indices[3 * src + 1], d->indices[3 * src + 2], ((uint32_t)d->tri_material[src] << 3) | mfl);
         }
         std::vector<uint32_t> mesh_flags(std::max<uint32_t>(d->n_meshes, 1), 0);
         for (uint32_t m = 0; m < d->n_meshes; ++m)
@@ -687,6 +693,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         UP(nodes4, dn4.data(), dn4.size());
         UP(top_nodes, top.data(), top.size());
         UP(tris, tris.data(), tris.size());
+        UP(prim_shade, prim_shade.data(), prim_shade.size());
         UP(indices, d->indices, 3 * (size_t)d->n_triangles);
         UP(points, d->points, 3 * (size_t)d->n_vertices);
         UP(normals, d->normals, d->normals ? 3 * (size_t)d->n_vertices : 0);
@@ -719,6 +726,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         ds.top_nodes = s->top_nodes.as<DevNode>();
         ds.n_top = (uint32_t)top.size();
         ds.tris = s->tris.as<float4>();
+        ds.prim_shade = s->prim_shade.as<uint4>();
         ds.spheres = d->n_spheres ? s->spheres.as<DevSphere>() : nullptr;
         ds.n_triangles = d->n_triangles;
         ds.root_ref = ref_of(0);
@@ -742,7 +750,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         ds.tex_info = d->n_textures ? s->tex_info.as<uint4>() : nullptr;
         s->on_device = true;
         s->info.upload_seconds = now_seconds() - u0;
-        DevBuf* all[] = {&s->nodes, &s->nodes4, &s->top_nodes, &s->tris, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
+        DevBuf* all[] = {&s->nodes, &s->nodes4, &s->top_nodes, &s->tris, &s->prim_shade, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
                          &s->mesh_flags, &s->materials, &s->lights, &s->spheres, &s->texels, &s->tex_info};
         for (DevBuf* b : all) s->info.device_bytes += b->bytes;
     }
@@ -753,7 +761,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
 void yk_scene_destroy(yk_scene* s) {
     if (!s) return;
     if (s->device >= 0) (void)hipSetDevice(s->device);
-    DevBuf* all[] = {&s->nodes, &s->nodes4, &s->top_nodes, &s->tris, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
+    DevBuf* all[] = {&s->nodes, &s->nodes4, &s->top_nodes, &s->tris, &s->prim_shade, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
                      &s->mesh_flags, &s->materials, &s->lights, &s->spheres, &s->texels, &s->tex_info};
     for (DevBuf* b : all) b->release();
     delete s;

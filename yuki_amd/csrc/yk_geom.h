@@ -171,10 +171,9 @@ YK_HD Surface make_surface_sphere(const DevSphere& sp, V3 ro, V3 rd, float t, V3
     return s;
 }
 
-YK_HD Surface make_surface(const DevScene& sc, uint32_t tri, const TriHit& h) {
-    uint32_t i0 = sc.indices[3 * tri], i1 = sc.indices[3 * tri + 1], i2 = sc.indices[3 * tri + 2];
-    V3 p0 = ld3(sc.points, i0), p1 = ld3(sc.points, i1), p2 = ld3(sc.points, i2);
-    uint32_t mflags = sc.mesh_flags[sc.tri_mesh[tri]];
+// SurfaceInteraction of a triangle hit from its vertices (world space), vertex indices (for
+// the per-vertex normals / uvs) and mesh flags
+YK_HD Surface make_surface_core(const DevScene& sc, V3 p0, V3 p1, V3 p2, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t mflags, const TriHit& h) {
     float u0x = 0.0f, u0y = 0.0f, u1x = 1.0f, u1y = 0.0f, u2x = 1.0f, u2y = 1.0f;  // triangle.rs:143-149
     if (mflags & YK_MESH_UVS) {
         u0x = sc.uvs[2 * i0]; u0y = sc.uvs[2 * i0 + 1];
@@ -225,6 +224,14 @@ YK_HD Surface make_surface(const DevScene& sc, uint32_t tri, const TriHit& h) {
         s.n = faceforward_n(s.n, s.ns);
         s.dpdus = ss;
     }
+    s.material = 0;
+    s.area_light = -1;
+    return s;
+}
+
+YK_HD Surface make_surface(const DevScene& sc, uint32_t tri, const TriHit& h) {
+    uint32_t i0 = sc.indices[3 * tri], i1 = sc.indices[3 * tri + 1], i2 = sc.indices[3 * tri + 2];
+    Surface s = make_surface_core(sc, ld3(sc.points, i0), ld3(sc.points, i1), ld3(sc.points, i2), i0, i1, i2, sc.mesh_flags[sc.tri_mesh[tri]], h);
     s.material = sc.tri_material[tri];
     s.area_light = sc.tri_area_light[tri];
     return s;
@@ -245,6 +252,32 @@ YK_HD Surface hit_surface(const DevScene& sc, uint32_t shape, V3 o, V3 d) {
     TriHit th = TriHit{0.0f, 0.0f, 0.0f, 0.0f};
     tri_intersect(o, rt, __builtin_inff(), ld3(sc.points, i0), ld3(sc.points, i1), ld3(sc.points, i2), th);
     Surface s = make_surface(sc, shape, th);
+    s.wo = -d;
+    return s;
+}
+
+// Same, addressed by the primitive's slot in leaf order (what the production traversal kernels
+// report): the 48-byte traversal record holds the vertices, the area light and the source
+// shape, DevScene::prim_shade the vertex indices, material and mesh flags — one dependent
+// fetch less than going through indices -> points and tri_mesh -> mesh_flags.
+YK_HD Surface hit_surface_prim(const DevScene& sc, uint32_t prim, V3 o, V3 d) {
+    const float4 v0 = sc.tris[3 * prim], v1 = sc.tris[3 * prim + 1], v2 = sc.tris[3 * prim + 2];
+    const uint4 ps = sc.prim_shade[prim];
+    const uint32_t src = __float_as_uint(v1.w);
+    if (__float_as_uint(v2.w) & YK_PRIM_SPHERE) {
+        const DevSphere& sp = sc.spheres[src - sc.n_triangles];
+        V3 ro, rd;
+        float t = 0.0f;
+        sphere_hit_t(sp, o, d, __builtin_inff(), t, ro, rd);
+        return make_surface_sphere(sp, ro, rd, t, d, sc.texels != nullptr);
+    }
+    RayTri rt = ray_tri_setup(d);
+    TriHit th = TriHit{0.0f, 0.0f, 0.0f, 0.0f};
+    const V3 p0 = V3{v0.x, v0.y, v0.z}, p1 = V3{v1.x, v1.y, v1.z}, p2 = V3{v2.x, v2.y, v2.z};
+    tri_intersect(o, rt, __builtin_inff(), p0, p1, p2, th);
+    Surface s = make_surface_core(sc, p0, p1, p2, ps.x, ps.y, ps.z, ps.w & 7u, th);
+    s.material = (int)(ps.w >> 3);
+    s.area_light = (int)__float_as_uint(v0.w);
     s.wo = -d;
     return s;
 }

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
             int tri = hit_tri[i];
             hit = tri >= 0;
             if (hit) {
-                sf = hit_surface(sc, (uint32_t)tri, o, d);
+                sf = hit_surface_prim(sc, (uint32_t)tri, o, d);  // `tri` is the leaf-order slot reported by the render-loop trace kernels
                 mat = sc.materials[sf.material];
                 if (mat.tex) {  // matte.rs:29-30: reflectance = kd.evaluate(si); no lobe when black
                     RGB kd = texture_eval(sc, mat.tex - 1u, sf.u, sf.v);
@@ -457,7 +457,7 @@ __global__ void k_debug_shade(DevScene sc, uint32_t integrator, PathBuffers cur,
         c = RGB{(float)s.x, (float)s.y, tri >= 0 ? (float)s.y : 0.0f};
     } else if (tri >= 0) {
         V3 o = f4_xyz(cur.rayO[i]), d = f4_xyz(cur.rayD[i]);
-        Surface sf = hit_surface(sc, (uint32_t)tri, o, d);
+        Surface sf = hit_surface_prim(sc, (uint32_t)tri, o, d);  // the normals integrators trace with the render-loop kernel: leaf-order slots
         V3 nn = integrator == YK_INTEGRATOR_GEOMETRY_NORMALS ? sf.n : sf.ns;
         c = RGB{nn.x, nn.y, nn.z} / 2.0f + 0.5f;
     }

@@ -127,7 +127,7 @@ __device__ __forceinline__ void pkt_closest_group(const DevScene& sc, PktStack& 
                         got = tri_intersect(r.o, r.rt, r.t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h);
                     }
                     if (got) {
-                        best = (int)__float_as_uint(v1.w);
+                        best = (int)prim;  // leaf-order slot, like the render-loop flavour of k_trace_closest_pt
                         r.t_max = h.t;
                     }
                 }
@@ -180,7 +180,7 @@ __device__ __forceinline__ void pkt_closest_group(const DevScene& sc, PktStack& 
     }
 }
 
-// Camera rays of one batch, 64 consecutive rays per packet.  hit_tri[i] = source shape or -1.
+// Camera rays of one batch, 64 consecutive rays per packet.  hit_tri[i] = primitive slot (leaf order) or -1.
 template <bool SPHERES>
 __global__ __launch_bounds__(YK_PKT_BLOCK, 8) void k_trace_closest_packet(DevScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
                                                                           const unsigned* count_ptr, unsigned* head, int* __restrict__ hit_tri,
