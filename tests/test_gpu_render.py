@@ -275,3 +275,38 @@ def test_render_one_tile_accumulating(ctx, yk, oracle):
     got, rays = it.render(yk.Scene(ctx, sd), cam, smp, tile, accumulating=True)
     want, wrays = oracle.OracleScene(sd).render_tiles_accumulating(cam.matrices, smp, integ, np.array([tile.bb], dtype=abi.TILE_DTYPE), [3])
     assert rays == wrays and np.array_equal(_bits(got), _bits(want))
+
+
+def test_bench_workload_at_full_size(ctx, yk, oracle):
+    """BASELINE config 3 exactly as bench.py runs it (1,024,012 triangles, SAH BVH, Path 8,
+    Stratified 8x8, 1920x1080): (1) the first 96 spiral tiles at full spp against the oracle,
+    bit for bit; (2) size-independent properties of the whole frame — the shard of rank 3 of 8
+    equals the same tiles of the full render, and the ray count is the sum over shards."""
+    sd = scenes.by_name("cfg3")
+    fs = yk.FilmSettings(res=(1920, 1080), tile_dim=16)
+    cam = yk.Camera(sd.camera, fs)
+    tiles = yk.film_tiles(fs)
+    sampler = yk.SamplerType.Stratified((8, 8), True, SEED)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=8))
+    it = yk.IntegratorType.instantiate(ctx, integ)
+    sc = yk.Scene(ctx, sd)
+    full, st_full = it.render_tiles(sc, cam, sampler, tiles)
+    assert np.isfinite(full).all() and st_full.samples == 1920 * 1080 * 64
+    offs = np.concatenate([[0], np.cumsum((tiles["x1"].astype(np.int64) - tiles["x0"]) * (tiles["y1"].astype(np.int64) - tiles["y0"]))])
+    # (1) oracle on a sample of the frame
+    k = 96
+    want, rays = oracle.OracleScene(sd).render_tiles(cam.matrices, sampler, integ, tiles[:k], n_threads=0)
+    got = full[: offs[k]]
+    assert _rmse(got, want) < TOL_RMSE
+    assert np.array_equal(_bits(got), _bits(want))
+    head, st_head = it.render_tiles(sc, cam, sampler, tiles[:k])
+    assert st_head.rays == rays and np.array_equal(_bits(head), _bits(got))
+    # (2) shards
+    total = 0
+    for r in (3,):
+        idx = np.arange(r, len(tiles), 8)
+        shard, st = it.render_tiles(sc, cam, sampler, tiles[idx])
+        ref = np.concatenate([full[offs[t] : offs[t + 1]] for t in idx])
+        assert np.array_equal(_bits(shard), _bits(ref))
+        total += st.rays
+    assert 0.11 < total / st_full.rays < 0.14
