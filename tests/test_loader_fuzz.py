@@ -1,0 +1,94 @@
+"""Malformed input never takes the parsers down: mutated PLY / pbrt-v3 / PNG files are either
+loaded or rejected with an error (the reference returns LoadError or panics; a C ABI must not
+crash).  The same corpus is run under AddressSanitizer by tools/asan/run.sh (CPU build)."""
+import os
+import random
+
+import numpy as np
+
+from yuki_amd import loaders
+from yuki_amd._ffi import YukiError
+
+import scene_files as sf
+
+
+def _seeds(d):
+    sf.write_ascii_ply(os.path.join(d, "a.ply"))
+    sf.write_binary_ply(os.path.join(d, "b.ply"))
+    sf.write_binary_ply(os.path.join(d, "c.ply"), ">")
+    sf.write_png(os.path.join(d, "p.png"), sf.test_pattern(9, 7))
+    sf.write_png(os.path.join(d, "q.png"), sf.test_pattern(9, 7, 16), depth=16, interlace=True, alpha=True)
+    pal = np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9], [10, 11, 12]], dtype=np.uint8)
+    sf.write_png(os.path.join(d, "r.png"), (np.arange(35).reshape(5, 7) % 4).astype(np.uint8), depth=2, palette=pal)
+    pb = sf.write_scene(d)
+    tx = sf.write_textured_scene(d)
+    rd = lambda p: open(p, "rb").read()
+    return {
+        "ply": [rd(os.path.join(d, n)) for n in ("a.ply", "b.ply", "c.ply")],
+        "png": [rd(os.path.join(d, n)) for n in ("p.png", "q.png", "r.png")],
+        "pbrt": [rd(pb), rd(tx)],
+    }
+
+
+def _mutate(rng, b):
+    b = bytearray(b)
+    for _ in range(rng.randint(1, 6)):
+        k = rng.random()
+        if k < 0.4 and b:
+            b[rng.randrange(len(b))] = rng.randrange(256)
+        elif k < 0.6 and b:
+            p = rng.randrange(len(b))
+            del b[p : p + rng.randint(1, 40)]
+        elif k < 0.8:
+            p = rng.randrange(len(b) + 1)
+            b[p:p] = bytes(rng.randrange(256) for _ in range(rng.randint(1, 20)))
+        elif b:
+            p = rng.randrange(len(b))
+            b[p : p + 4] = rng.choice([b"\xff\xff\xff\xff", b"\x00\x00\x00\x00", b"\x7f\xff\xff\xff", b"9999", b"-1  "])
+    return bytes(b)
+
+
+def write_corpus(d, seed=1, count=1000):
+    """Mutated files fzNNNNN.{ply,png,pbrt} next to the seed files (so Include / plymesh /
+    imagemap references inside mutated pbrt files still resolve)."""
+    rng = random.Random(seed)
+    seeds = _seeds(d)
+    paths = []
+    for i in range(count):
+        kind = rng.choice(["ply", "png", "pbrt"])
+        p = os.path.join(d, f"fz{i:05d}.{kind}")
+        with open(p, "wb") as f:
+            f.write(_mutate(rng, rng.choice(seeds[kind])))
+        paths.append(p)
+    return paths
+
+
+def test_mutated_files_are_loaded_or_rejected(tmp_path):
+    loaded = rejected = 0
+    for p in write_corpus(str(tmp_path), seed=3, count=600):
+        try:
+            if p.endswith(".ply"):
+                loaders.load_ply(p)
+            elif p.endswith(".png"):
+                loaders.load_image_texture(p)
+            else:
+                loaders.load_pbrt(p)
+            loaded += 1
+        except YukiError as e:
+            assert e.status in (1, 5), (p, e)  # INVALID_ARGUMENT or UNSUPPORTED, with a message
+            assert str(e)
+            rejected += 1
+    assert loaded > 5 and rejected > 300
+
+
+def test_directories_and_empty_files_are_rejected(tmp_path):
+    (tmp_path / "empty.ply").write_bytes(b"")
+    (tmp_path / "empty.pbrt").write_bytes(b"")
+    (tmp_path / "empty.png").write_bytes(b"")
+    for fn, p in ((loaders.load_ply, tmp_path), (loaders.load_pbrt, tmp_path), (loaders.load_image_texture, tmp_path), (loaders.load_ply, tmp_path / "empty.ply"),
+                  (loaders.load_pbrt, tmp_path / "empty.pbrt"), (loaders.load_image_texture, tmp_path / "empty.png")):
+        try:
+            fn(str(p))
+            raise AssertionError("accepted " + str(p))
+        except YukiError:
+            pass

@@ -9,6 +9,10 @@
 // f32 arithmetic in the reference's operation order; built with -ffp-contract=off.
 #include "yk_host.h"
 
+#include <sys/stat.h>
+
+#include <cstdio>
+
 #include <cmath>
 #include <cstring>
 #include <utility>
@@ -18,6 +22,20 @@
 #include "yk_math.h"
 
 namespace yk {
+
+bool read_file(const std::string& path, std::vector<unsigned char>& out) {
+    out.clear();
+    struct stat sb;
+    if (stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 0 || (unsigned long long)sb.st_size > (2ull << 30)) return false;
+    std::FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    out.resize((size_t)sb.st_size);
+    const size_t got = out.empty() ? 0 : std::fread(out.data(), 1, out.size(), f);
+    std::fclose(f);
+    out.resize(got);
+    return true;
+}
+
 
 // ------------------------------------------------------------------ matrices
 bool mat4_inverse(const float* src, float* out) {

@@ -29,6 +29,9 @@ bool mat4_inverse(const float* m, float* out);  // matrix.rs:107-215
 yk_status camera_init(const yk_camera_params* p, yk_camera* out);
 std::vector<yk_tile> film_tiles(uint16_t res_x, uint16_t res_y, uint16_t tile_dim);
 
+// Whole regular file into memory; false for directories, unreadable files and files > 2 GiB.
+bool read_file(const std::string& path, std::vector<unsigned char>& out);
+
 // ---- BVH ---------------------------------------------------------------------
 struct ShapeBounds {
     float bmin[3], bmax[3];

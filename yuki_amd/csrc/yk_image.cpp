@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/yuki_hip.h"
+#include "yk_host.h"
 
 namespace {
 
@@ -322,13 +323,17 @@ yk_status decode_png(const std::vector<uint8_t>& f, uint32_t& W, uint32_t& H, st
 
 // used by the pbrt loader (yk_loaders.cpp)
 yk_status yk_image_decode_file(const std::string& path, uint32_t& w, uint32_t& h, std::vector<float>& rgb, std::string& err) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) {
+    std::vector<uint8_t> bytes;
+    if (!yk::read_file(path, bytes)) {
         err = "Could not open '" + path + "'";
         return YK_ERR_INVALID_ARGUMENT;
     }
-    std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-    yk_status st = decode_png(bytes, w, h, rgb);
+    yk_status st;
+    try {
+        st = decode_png(bytes, w, h, rgb);
+    } catch (const std::exception& e) {
+        st = ifail(YK_ERR_INVALID_ARGUMENT, std::string("PNG: ") + e.what());
+    }
     if (st != YK_OK) err = g_image_error + " (" + path + ")";
     return st;
 }

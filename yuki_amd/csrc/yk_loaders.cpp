@@ -212,9 +212,8 @@ struct PlyReader {
 
 // ply::load (scene/ply.rs:19-130).  `fit`: no transform given -> scale/translate into the unit cube.
 static yk_status load_ply_mesh(const std::string& path, const Xf* transform, yk_loaded_scene& s, int material) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) return lfail(YK_ERR_INVALID_ARGUMENT, "Could not open '" + path + "'");
-    std::vector<unsigned char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    std::vector<unsigned char> buf;
+    if (!read_file(path, buf)) return lfail(YK_ERR_INVALID_ARGUMENT, "Could not open '" + path + "'");
     // ---- header
     size_t pos = 0;
     auto next_line = [&](std::string& line) -> bool {
@@ -643,10 +642,10 @@ struct Failure {
 
 static yk_status load_pbrt_file(const std::string& path, yk_loaded_scene& s, PbrtState& S, int depth) {
     if (depth > 32) return lfail(YK_ERR_INVALID_ARGUMENT, "Include nesting too deep");
-    std::ifstream f(path, std::ios::binary);
-    if (!f) return lfail(YK_ERR_INVALID_ARGUMENT, "Could not open '" + path + "'");
+    std::vector<unsigned char> bytes;
+    if (!read_file(path, bytes)) return lfail(YK_ERR_INVALID_ARGUMENT, "Could not open '" + path + "'");
     Lexer lx;
-    lx.in.assign((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    lx.in.assign(bytes.begin(), bytes.end());
     std::string parent = ".";
     {
         size_t slash = path.find_last_of('/');
@@ -757,8 +756,9 @@ static yk_status load_pbrt_file(const std::string& path, yk_loaded_scene& s, Pbr
                 std::vector<float> values;
                 Tok a = next();
                 if (a.kind == Tok::String) {
-                    std::ifstream sf(parent + "/" + a.text);
-                    if (!sf) throw fail(YK_ERR_INVALID_ARGUMENT, "Could not open spd '" + a.text + "'");
+                    std::vector<unsigned char> spd;
+                    if (!read_file(parent + "/" + a.text, spd)) throw fail(YK_ERR_INVALID_ARGUMENT, "Could not open spd '" + a.text + "'");
+                    std::istringstream sf(std::string(spd.begin(), spd.end()));
                     std::string l;
                     while (std::getline(sf, l)) {
                         std::istringstream ls(l.substr(0, l.find('#')));
@@ -992,7 +992,12 @@ yk_status yk_load_ply(const char* path, uint32_t split_method, uint32_t max_shap
     s->max_shapes_in_node = max_shapes_in_node;
     const float white[3] = {1, 1, 1};
     s->materials.push_back(make_mat(YK_MAT_MATTE, white, nullptr, 0.0f, false));  // scene/mod.rs:104-107
-    yk_status st = load_ply_mesh(path, nullptr, *s, 0);
+    yk_status st;
+    try {
+        st = load_ply_mesh(path, nullptr, *s, 0);
+    } catch (const std::exception& e) {  // e.g. bad_alloc on an absurd element count
+        st = lfail(YK_ERR_INVALID_ARGUMENT, std::string("PLY: ") + e.what());
+    }
     if (st != YK_OK) {
         delete s;
         return st;
@@ -1022,7 +1027,12 @@ yk_status yk_load_pbrt(const char* path, uint32_t split_method, uint32_t max_sha
     PbrtState S;
     get_material("matte", ParamSet(), S.textures, def);
     s->materials.push_back(def);  // default_material
-    yk_status st = load_pbrt_file(path, *s, S, 0);
+    yk_status st;
+    try {
+        st = load_pbrt_file(path, *s, S, 0);
+    } catch (const std::exception& e) {
+        st = lfail(YK_ERR_INVALID_ARGUMENT, std::string("pbrt: ") + e.what());
+    }
     if (st != YK_OK) {
         delete s;
         return st;
