@@ -140,6 +140,40 @@ class Scene {
     yk_scene* h_ = nullptr;
 };
 
+// scene::pbrt::load / Scene::ply (scene/pbrt/mod.rs:94, scene/mod.rs:99): the parsed scene as a
+// ready yk_scene_desc plus the CameraParameters and FilmSettings the reference's loaders return
+class LoadedScene {
+   public:
+    enum class Format { Ply, Pbrt };
+    LoadedScene(const std::string& path, Format format, uint32_t split_method = YK_SPLIT_SAH, uint32_t max_shapes_in_node = 1) {
+        yk_status st = format == Format::Ply ? yk_load_ply(path.c_str(), split_method, max_shapes_in_node, &h_) : yk_load_pbrt(path.c_str(), split_method, max_shapes_in_node, &h_);
+        if (st != YK_OK) throw Error(st, yk_loader_last_error());
+        uint16_t tile_dim = 16;
+        yk_camera_params cp;
+        check(yk_loaded_scene_get(h_, &desc, &cp, &tile_dim));
+        camera.position = {cp.position[0], cp.position[1], cp.position[2]};
+        camera.target = {cp.target[0], cp.target[1], cp.target[2]};
+        camera.up = {cp.up[0], cp.up[1], cp.up[2]};
+        camera.fov_axis = cp.fov_axis == 0 ? FoV::X : FoV::Y;
+        camera.fov_degrees = cp.fov_degrees;
+        film.res_x = cp.res_x;
+        film.res_y = cp.res_y;
+        film.tile_dim = tile_dim;
+    }
+    ~LoadedScene() { yk_loaded_scene_destroy(h_); }
+    LoadedScene(const LoadedScene&) = delete;
+    LoadedScene& operator=(const LoadedScene&) = delete;
+    yk_scene_desc desc{};  // valid while this object lives; pass to Scene(ctx, desc)
+    CameraParameters camera;
+    FilmSettings film;
+
+   private:
+    yk_loaded_scene* h_ = nullptr;
+};
+
+// app/util.rs:90-111
+inline void write_exr(const std::string& path, uint32_t width, uint32_t height, const float* rgb) { check(yk_write_exr(path.c_str(), width, height, rgb)); }
+
 // trait Integrator, integrators/mod.rs:92-186
 class Integrator {
    public:
@@ -155,6 +189,17 @@ class Integrator {
                                  yk_cancel_fn cancel = nullptr, void* user = nullptr) const {
         yk_render_stats st{};
         check(yk_render_tiles(ctx_.handle(), scene.handle(), &camera.matrices, &sampler, &desc_, tiles.data(), tiles.size(), out_rgb, &st, cancel, user), ctx_.handle());
+        return st;
+    }
+
+    // Integrator::render(accumulating = true): one sample (global index tile_samples[t]) per pixel, raw value
+    yk_render_stats render_tiles_accumulating(const Scene& scene, const Camera& camera, const yk_sampler_desc& sampler, const std::vector<FilmTile>& tiles,
+                                              const std::vector<uint16_t>& tile_samples, float* out_rgb) const {
+        if (tile_samples.size() != tiles.size()) throw Error(YK_ERR_INVALID_ARGUMENT, "one sample index per tile");
+        yk_render_stats st{};
+        check(yk_render_tiles_accumulating(ctx_.handle(), scene.handle(), &camera.matrices, &sampler, &desc_, tiles.data(), tile_samples.data(), tiles.size(), out_rgb, &st,
+                                           nullptr, nullptr),
+              ctx_.handle());
         return st;
     }
 

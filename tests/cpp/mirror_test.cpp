@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "yuki_hip.hpp"
@@ -69,6 +70,19 @@ int main(int argc, char** argv) {
         std::printf("bad_scene=status%d\n", (int)e.status);
     }
     d.max_shapes_in_node = 1;
+    // scene::pbrt::load through the mirror (argv[2] = a .pbrt file written by the test)
+    if (argc > 2) {
+        LoadedScene ls(argv[2], LoadedScene::Format::Pbrt);
+        Scene loaded(nullptr, ls.desc);
+        std::printf("pbrt_triangles=%u pbrt_spheres=%u pbrt_lights=%u pbrt_res=%ux%u pbrt_fov=%.1f pbrt_nodes=%llu\n", ls.desc.n_triangles, ls.desc.n_spheres, ls.desc.n_lights,
+                    ls.film.res_x, ls.film.res_y, ls.camera.fov_degrees, (unsigned long long)loaded.info().n_nodes);
+        try {
+            LoadedScene missing(std::string(argv[2]) + ".nope", LoadedScene::Format::Pbrt);
+            std::printf("missing_scene=accepted\n");
+        } catch (const Error& e) {
+            std::printf("missing_scene=status%d\n", (int)e.status);
+        }
+    }
     if (!gpu) return 0;
 
     Context ctx(0);
@@ -86,6 +100,17 @@ int main(int argc, char** argv) {
     int w = tiles[0].x1 - tiles[0].x0, h = tiles[0].y1 - tiles[0].y0;
     bool same = std::memcmp(tile_px.data(), film.data(), (size_t)w * h * 12) == 0;
     std::printf("tile_rays=%zu tile_matches_batch=%d\n", rays, same ? 1 : 0);
+    // accumulating film: the sum of the four sample passes / 4 equals the plain render
+    {
+        std::vector<float> acc(film.size(), 0.0f), pass(film.size());
+        for (uint16_t sidx = 0; sidx < 4; ++sidx) {
+            path.render_tiles_accumulating(scene, cam, smp, tiles, std::vector<uint16_t>(tiles.size(), sidx), pass.data());
+            for (size_t k = 0; k < acc.size(); ++k) acc[k] += pass[k];
+        }
+        bool eq = true;
+        for (size_t k = 0; k < acc.size(); ++k) eq = eq && (acc[k] / 4.0f == film[k]);
+        std::printf("accumulate_matches_plain=%d\n", eq ? 1 : 0);
+    }
     try {
         FilmTile bad{8, 8, 8, 12};
         path.render(scene, cam, smp, bad, tile_px.data());

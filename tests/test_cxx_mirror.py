@@ -25,8 +25,22 @@ def _kv(out):
 
 
 def test_cxx_mirror_host_side(tmp_path, yk):
-    out = subprocess.check_output([_build(tmp_path)], text=True)
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scene_files as sf
+
+    pbrt = sf.write_scene(str(tmp_path / "scene"))
+    out = subprocess.check_output([_build(tmp_path), "cpu", pbrt], text=True)
     kv = _kv(out)
+    # LoadedScene (scene::pbrt::load through the C++ mirror) agrees with the Python binding
+    from yuki_amd import loaders
+
+    sd, cam_p, film = loaders.load_pbrt(pbrt)
+    assert int(kv["pbrt_triangles"]) == sd.n_triangles and int(kv["pbrt_spheres"]) == len(sd.spheres) and int(kv["pbrt_lights"]) == len(sd.light_structs)
+    assert kv["pbrt_res"] == "%dx%d" % film.res and float(kv["pbrt_fov"]) == cam_p.fov_degrees
+    assert int(kv["pbrt_nodes"]) == yk.Scene(None, sd).info().n_nodes
+    assert kv["missing_scene"] == "status1"
     assert kv["tiles"] == "6" and kv["first"] == "16,0"  # 3x2 tiles, spiral starts at the centre tile (film.rs:343-346)
     assert kv["nodes"] == "3" and kv["shapes"] == "4"  # each quad = 2 triangles with identical bounds -> one 2-shape leaf (bvh.rs:334-345)
     assert kv["bad_scene"] == "status1"
@@ -42,3 +56,4 @@ def test_cxx_mirror_renders(tmp_path):
     assert float(kv["mean"]) > 0.05
     assert kv["tile_matches_batch"] == "1" and int(kv["tile_rays"]) > 0
     assert kv["bad_tile"] == "status1"
+    assert kv["accumulate_matches_plain"] == "1"
