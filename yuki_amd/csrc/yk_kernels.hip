@@ -114,16 +114,19 @@ __global__ void k_raygen_user(RenderParams prm, const float* ray_o, const float*
 // "dequeue") and made this kernel atomic-bound (profiles/r01_a_*: 0.178 s/frame,
 // 79 % of wave cycles waiting).
 #ifndef SHADE_CAP
-#define SHADE_CAP 512  // staged entries per block (paths and shadow rays each)
+#define SHADE_CAP 384  // staged continuation paths per block (64 B each)
+#endif
+#ifndef SHADE_CAPQ
+#define SHADE_CAPQ 768  // staged shadow rays per block (36 B each): a whole iteration of 256 paths x 3 lights fits
 #endif
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 1  // waves per SIMD the register allocator must leave room for (blocks of 256 threads)
 #endif
-template <int CAP> struct ShadeStaging {
+template <int CAP, int CAPQ> struct ShadeStaging {
     float4 pO[CAP], pD[CAP], pT[CAP];
     uint4 pR[CAP];
-    float4 qO[CAP], qD[CAP];
-    unsigned qS[CAP];
+    float4 qO[CAPQ], qD[CAPQ];
+    unsigned qS[CAPQ];
     unsigned fill_p, fill_q, gbase;
     unsigned q_delta;  // class of the staged shadow rays: 1 = towards a point/spot/distant light
 };
@@ -141,12 +144,12 @@ __device__ __forceinline__ unsigned block_append(bool want, unsigned* lds_fill) 
 
 __device__ __forceinline__ unsigned valid_light_kind(const DevScene& sc, unsigned l) { return sc.lights[l].kind; }
 
-template <int BLOCK, int CAP>
+template <int BLOCK, int CAP, int CAPQ>
 __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                                                  PathBuffers cur, PathBuffers nxt,
                                                  const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis,
                                                  unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* ctrl, unsigned cur_slot, unsigned split_delta) {
-    __shared__ ShadeStaging<CAP> stg;
+    __shared__ ShadeStaging<CAP, CAPQ> stg;
     const unsigned n = ctrl[cur_slot];
     const unsigned nl = sc.n_lights;
     unsigned* next_count = ctrl + (cur_slot ^ 1u);
@@ -192,11 +195,24 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
         if (threadIdx.x == 0) stg.fill_p = 0;
         __syncthreads();
     };
+    // When a whole iteration's shadow rays fit the staging buffer and they all go to one queue,
+    // the flush decisions are taken once per iteration instead of once per light (the barriers
+    // of the per-light decisions cost more than the math between them).
+    const bool per_iter = !split_delta && BLOCK * nl <= (unsigned)CAPQ;
     // all lanes stay in the loop together so the ballots below see whole waves
     const unsigned n_round = (n + BLOCK - 1) / BLOCK * BLOCK;
     for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += gridDim.x * BLOCK) {
         const bool valid = i < n;
         bool alive = false;
+        if (per_iter) {
+            // ONE block-wide decision per iteration: room for every shadow ray (BLOCK x nl) and every
+            // continuation (BLOCK) this iteration can stage, so the appends below need no barriers
+            __syncthreads();
+            const unsigned fq = stg.fill_q, fp = stg.fill_p, staged = stg.q_delta;
+            __syncthreads();
+            if (fq && fq + BLOCK * nl > CAPQ) flush_q(fq, staged);
+            if (fp + BLOCK > CAP) flush_p(fp);
+        }
         float4 nO = make_float4(0, 0, 0, 0), nD = nO, nT = nO;
         uint4 nR = make_uint4(0, 0, 0, 0);
         // per-light scratch lives in registers only for the current light
@@ -279,12 +295,12 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
             if (valid) vis[slot] = want ? 1 : 0;
             // shadow rays are appended densely (coalesced for the any-hit kernel); the
             // contribution stays at its (path, light) slot for `accumulate`
-            __syncthreads();
-            {
+            if (!per_iter) {
+                __syncthreads();
                 const unsigned f = stg.fill_q, staged = stg.q_delta;
                 const unsigned delta = (split_delta && valid_light_kind(sc, l) != YK_LIGHT_RECT) ? 1u : 0u;
                 __syncthreads();  // every wave has read the same fill before any wave appends again
-                if (f && (staged != delta || f + BLOCK > CAP)) flush_q(f, staged);
+                if (f && (staged != delta || f + BLOCK > CAPQ)) flush_q(f, staged);
                 if (threadIdx.x == 0) stg.q_delta = delta;
             }
             unsigned q = block_append(want, &stg.fill_q);
@@ -342,8 +358,8 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
             pend[i] = make_float4(term.r, term.g, term.b, __uint_as_float(kind));
         }
         // ---- stream compaction of the survivors into the other buffer
-        __syncthreads();
-        {
+        if (!per_iter) {
+            __syncthreads();
             const unsigned f = stg.fill_p;
             __syncthreads();
             if (f + BLOCK > CAP) flush_p(f);
@@ -568,7 +584,7 @@ void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const Render
                   PathBuffers cur, PathBuffers nxt,
                   const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis, unsigned* shq, float4* shO2,
                   float4* shD2, unsigned* shq2, unsigned* ctrl, unsigned cur_slot, unsigned split_delta) {
-    hipLaunchKernelGGL((k_shade<256, SHADE_CAP>), dim3(grid), dim3(256), 0, s, sc, prm, pixel_xy, sample_index_tab, cur, nxt, hit_tri, pend, shO, shD, shC, vis, shq,
+    hipLaunchKernelGGL((k_shade<256, SHADE_CAP, SHADE_CAPQ>), dim3(grid), dim3(256), 0, s, sc, prm, pixel_xy, sample_index_tab, cur, nxt, hit_tri, pend, shO, shD, shC, vis, shq,
                        shO2, shD2, shq2, ctrl, cur_slot, split_delta);
 }
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
