@@ -310,3 +310,11 @@ def test_bench_workload_at_full_size(ctx, yk, oracle):
         assert np.array_equal(_bits(shard), _bits(ref))
         total += st.rays
     assert 0.11 < total / st_full.rays < 0.14
+
+
+def test_max_depth_zero_renders_black(ctx, yk, oracle):
+    """`while bounces < max_depth` never runs (path.rs:85): no rays, zero radiance."""
+    sd = scenes.by_name("city-tiny")
+    got, stats, want, rays = _render_both(ctx, yk, oracle, sd, (48, 32), yk.SamplerType.Uniform(2, SEED), yk.IntegratorType.Path(yk.PathParams(max_depth=0)))
+    assert stats.rays == rays == 0
+    assert not got.any() and np.array_equal(_bits(got), _bits(want))
