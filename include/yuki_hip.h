@@ -215,7 +215,8 @@ yk_status yk_last_error(const yk_context* ctx, char* buf, size_t cap);
 /* tuning knobs (none changes any result): "batch_paths" (camera samples per batch),
  * "streams" (1|2 work sets), "sample_buf_cap" (bytes), "time_kernels" (0|1),
  * "packet_bounces" / "packet_shadow_bounces" (leading bounces traced by the wave-packet
- * kernels), "overlap_shadow" (0|1), "top_nodes" (tree-top nodes the traversal kernels keep
+ * kernels), "overlap_shadow" (0|1), "shade_reorder" (0|1: paths of a shade block dealt to
+ * lanes by material kind), "top_nodes" (tree-top nodes the traversal kernels keep
  * in LDS, 0..255) and "wide_bvh" (0|1: traverse the 4-wide collapse of the BVH) — the last
  * two apply to scenes created afterwards. */
 yk_status yk_context_set_option(yk_context* ctx, const char* key, int64_t value);

@@ -55,6 +55,7 @@ struct yk_context {
     int64_t batch_paths = 128 << 20;
     int64_t packet_bounces = 1;         // leading bounces whose closest-hit rays use the wave-packet kernel (camera rays are coherent); 0 = never
     int64_t packet_shadow_bounces = 1;  // same for the shadow rays towards point / spot / distant lights (their own queue)
+    int64_t shade_reorder = 1;   // deal the paths of a shade block to its lanes sorted by material kind (bounces > 0)
     int64_t overlap_shadow = 1;  // run {trace_any, accumulate}(b) on a side stream beside trace_closest(b+1)
     int64_t wide_bvh = 0;   // traverse the 4-wide collapse of the BVH (scenes created afterwards)
     int64_t top_nodes = YK_TOP_MAX; // interior nodes (capped by what the kernels were built for) of the first tree levels the traversal kernels keep in LDS
@@ -234,6 +235,8 @@ yk_status yk_context_set_option(yk_context* ctx, const char* key, int64_t value)
     } else if (k == "packet_shadow_bounces") {
         if (value < 0) return YK_ERR_INVALID_ARGUMENT;
         ctx->packet_shadow_bounces = value;
+    } else if (k == "shade_reorder") {
+        ctx->shade_reorder = value != 0;
     } else if (k == "overlap_shadow") {
         ctx->overlap_shadow = value != 0;
     } else if (k == "top_nodes") {
@@ -422,7 +425,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
     for (uint32_t m = 0; m < d->n_materials; ++m)
         if ((d->materials[m].flags & YK_MAT_FLAG_TEXTURED_A) && d->materials[m].kind == YK_MAT_MATTE && d->materials[m].a_texture >= d->n_textures)
             return fail(ctx, YK_ERR_INVALID_ARGUMENT, "material texture index out of range");
-    if (d->n_materials >= (1u << 29)) return fail(ctx, YK_ERR_UNSUPPORTED, "more than 2^29 materials");
+    if (d->n_materials >= (1u << 26)) return fail(ctx, YK_ERR_UNSUPPORTED, "more than 2^26 materials");
     for (uint32_t t = 0; t < d->n_textures; ++t)
         if (!d->textures || !d->textures[t].rgb || d->textures[t].width == 0 || d->textures[t].height == 0 || d->textures[t].width >= (1u << 24) ||
             d->textures[t].height >= (1u << 24))
@@ -625,6 +628,8 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         const size_t np = s->bvh.shape_order.size();
         std::vector<float4> tris(3 * np);
         std::vector<uint4> prim_shade(np);
+        std::vector<uint32_t> mat_kind(std::max<uint32_t>(d->n_materials, 1), 0u);  // device BSDF kind (MK_*) per material
+        for (uint32_t m = 0; m < d->n_materials; ++m) mat_kind[m] = make_material(d->materials[m]).kind & 7u;
         std::vector<uint8_t> last(np, 0);
         for (const yk_bvh_node& n : nodes)
             if (n.is_leaf) last[(size_t)n.a + n.count - 1] = 1;
@@ -639,7 +644,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
                 tris[3 * p + 0] = make_float4(0.0f, 0.0f, 0.0f, w0);
                 tris[3 * p + 1] = make_float4(0.0f, 0.0f, 0.0f, w1);
                 tris[3 * p + 2] = make_float4(0.0f, 0.0f, 0.0f, w2);
-                prim_shade[p] = make_uint4(0u, 0u, 0u, (uint32_t)d->spheres[src - d->n_triangles].material << 3);
+                prim_shade[p] = make_uint4(0u, 0u, 0u, ((uint32_t)d->spheres[src - d->n_triangles].material << 6) | (mat_kind[d->spheres[src - d->n_triangles].material] << 3));
                 continue;
             }
             const float* p0 = d->points + 3 * (size_t)d->indices[3 * src];
@@ -656,7 +661,8 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
             tris[3 * p + 2] = make_float4(p2[0], p2[1], p2[2], w2);
             const yk_mesh_desc& md = d->meshes[d->tri_mesh ? d->tri_mesh[src] : 0];
             const uint32_t mfl = (md.has_normals ? YK_MESH_NORMALS : 0u) | (md.has_uvs ? YK_MESH_UVS : 0u) | (md.swaps_handedness ? YK_MESH_SWAPS : 0u);
-            prim_shade[p] = make_uint4(d->indices[3 * src], d->indices[3 * src + 1], d->indices[3 * src + 2], ((uint32_t)d->tri_material[src] << 3) | mfl);
+            prim_shade[p] = make_uint4(d->indices[3 * src], d->indices[3 * src + 1], d->indices[3 * src + 2],
+                                       ((uint32_t)d->tri_material[src] << 6) | (mat_kind[d->tri_material[src]] << 3) | mfl);
         }
         std::vector<uint32_t> mesh_flags(std::max<uint32_t>(d->n_meshes, 1), 0);
         for (uint32_t m = 0; m < d->n_meshes; ++m)
@@ -925,7 +931,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         e = kt.begin(st);
         launch_shade(st, sg, ds, prm, pixel_xy, sample_index_tab, pc, pn, ws.hit.as<int>(), ws.pend.as<float4>(), ws.shO.as<float4>(),
                      ws.shD.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ws.shq.as<unsigned>(), ws.shO2.as<float4>(),
-                     ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), ctrl, cur, split ? 1u : 0u);
+                     ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), ctrl, cur, split ? 1u : 0u, (b > 0 && ctx->shade_reorder) ? 1u : 0u);
         kt.end(e, 2, st);
         if (overlap) {
             (void)hipEventRecord(ws.ev_shade, st);

@@ -102,7 +102,7 @@ struct DevScene {
     const DevNode* top_nodes;  // breadth-first copy of the first n_top interior nodes; child refs carry YK_TOP_BIT inside the set
     uint32_t n_top;
     const float4* tris;  // 3 per primitive in leaf order: (p0, bits(area_light)) (p1, bits(source shape)) (p2, bits(YK_PRIM_*))
-    const uint4* prim_shade;   // per primitive in leaf order: (i0, i1, i2, material << 3 | YK_MESH_* flags); spheres: (0,0,0, material << 3)
+    const uint4* prim_shade;   // per primitive in leaf order: (i0, i1, i2, material << 6 | material kind (MK_*) << 3 | YK_MESH_* flags)
     const DevSphere* spheres;  // source shape s >= n_triangles is spheres[s - n_triangles]
     uint32_t n_triangles;
     uint32_t root_ref;

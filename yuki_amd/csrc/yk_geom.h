@@ -276,7 +276,7 @@ YK_HD Surface hit_surface_prim(const DevScene& sc, uint32_t prim, V3 o, V3 d) {
     const V3 p0 = V3{v0.x, v0.y, v0.z}, p1 = V3{v1.x, v1.y, v1.z}, p2 = V3{v2.x, v2.y, v2.z};
     tri_intersect(o, rt, __builtin_inff(), p0, p1, p2, th);
     Surface s = make_surface_core(sc, p0, p1, p2, ps.x, ps.y, ps.z, ps.w & 7u, th);
-    s.material = (int)(ps.w >> 3);
+    s.material = (int)(ps.w >> 6);
     s.area_light = (int)__float_as_uint(v0.w);
     s.wo = -d;
     return s;

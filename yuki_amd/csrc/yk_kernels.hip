@@ -120,7 +120,7 @@ __global__ void k_raygen_user(RenderParams prm, const float* ray_o, const float*
 #define SHADE_CAPQ 768  // staged shadow rays per block (36 B each): a whole iteration of 256 paths x 3 lights fits
 #endif
 #ifndef SHADE_MIN_WAVES
-#define SHADE_MIN_WAVES 1  // waves per SIMD the register allocator must leave room for (blocks of 256 threads)
+#define SHADE_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (blocks of 256 threads)
 #endif
 template <int CAP, int CAPQ> struct ShadeStaging {
     float4 pO[CAP], pD[CAP], pT[CAP];
@@ -129,6 +129,8 @@ template <int CAP, int CAPQ> struct ShadeStaging {
     unsigned qS[CAPQ];
     unsigned fill_p, fill_q, gbase;
     unsigned q_delta;  // class of the staged shadow rays: 1 = towards a point/spot/distant light
+    unsigned bucket[8];          // material-kind histogram of the iteration's 256 paths
+    unsigned short order[256];   // sorted position -> lane whose path it is
 };
 
 // every thread of the block calls this (converged); returns the staging position
@@ -148,7 +150,7 @@ template <int BLOCK, int CAP, int CAPQ>
 __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                                                  PathBuffers cur, PathBuffers nxt,
                                                  const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis,
-                                                 unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* ctrl, unsigned cur_slot, unsigned split_delta) {
+                                                 unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* ctrl, unsigned cur_slot, unsigned split_delta, unsigned reorder) {
     __shared__ ShadeStaging<CAP, CAPQ> stg;
     const unsigned n = ctrl[cur_slot];
     const unsigned nl = sc.n_lights;
@@ -201,7 +203,26 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
     const bool per_iter = !split_delta && BLOCK * nl <= (unsigned)CAPQ;
     // all lanes stay in the loop together so the ballots below see whole waves
     const unsigned n_round = (n + BLOCK - 1) / BLOCK * BLOCK;
-    for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < n_round; i += gridDim.x * BLOCK) {
+    for (unsigned i0 = blockIdx.x * BLOCK + threadIdx.x; i0 < n_round; i0 += gridDim.x * BLOCK) {
+        unsigned i = i0;
+        if (reorder) {
+            // After the first bounce the 64 paths of a wave hit surfaces of five material kinds and
+            // every wave runs every kind's BSDF code (measured: 166 ps per path against 110 ps when all
+            // materials are one Lambert).  The block's 256 paths are therefore dealt to the lanes
+            // sorted by the material kind of what they hit: a wave sees one or two kinds.  Which lane
+            // shades which path has no influence on any result.
+            const int t = i0 < n ? hit_tri[i0] : -1;
+            const unsigned key = i0 >= n ? 7u : (t < 0 ? 6u : ((sc.prim_shade[t].w >> 3) & 7u));
+            if (threadIdx.x < 8) stg.bucket[threadIdx.x] = 0;
+            __syncthreads();
+            const unsigned rank = atomicAdd(&stg.bucket[key], 1u);
+            __syncthreads();
+            unsigned base = 0;
+            for (unsigned k = 0; k < key; ++k) base += stg.bucket[k];
+            stg.order[base + rank] = (unsigned short)threadIdx.x;
+            __syncthreads();
+            i = (i0 - threadIdx.x) + stg.order[threadIdx.x];
+        }
         const bool valid = i < n;
         bool alive = false;
         if (per_iter) {
@@ -583,9 +604,9 @@ void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, 
 void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                   PathBuffers cur, PathBuffers nxt,
                   const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis, unsigned* shq, float4* shO2,
-                  float4* shD2, unsigned* shq2, unsigned* ctrl, unsigned cur_slot, unsigned split_delta) {
+                  float4* shD2, unsigned* shq2, unsigned* ctrl, unsigned cur_slot, unsigned split_delta, unsigned reorder) {
     hipLaunchKernelGGL((k_shade<256, SHADE_CAP, SHADE_CAPQ>), dim3(grid), dim3(256), 0, s, sc, prm, pixel_xy, sample_index_tab, cur, nxt, hit_tri, pend, shO, shD, shC, vis, shq,
-                       shO2, shD2, shq2, ctrl, cur_slot, split_delta);
+                       shO2, shD2, shq2, ctrl, cur_slot, split_delta, reorder);
 }
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
                        const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* ctrl, unsigned cur_slot) {
