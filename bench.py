@@ -13,7 +13,11 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): the film's spiral
 tile list (film.rs:333-376) is dealt round-robin to the ranks, the scene is
 replicated, each rank renders its tiles into HBM and one RCCL gather moves the
 per-tile radiance to rank 0, which scatters it into the film (Film::update_tile).
-Total work is fixed -> "scaling": "strong".
+Total work is fixed -> "scaling": "strong".  Steps are enqueued without host
+synchronisation, alternately on two contexts (frames in flight = 2), so the latency
+tail of one step overlaps the bulk of the next; N = 1 times synchronous steps (live
+per-kernel HIP-event timings) and reports the two-in-flight rate beside them in
+`extra.two_in_flight`.
 
 Metric = the reference's own: closest-hit rays / second (path.rs:87,
 app/window.rs:911-916); shadow rays are traced but not counted.
@@ -29,6 +33,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps streams onto 4 hardware queues by default and streams that share a queue serialise;
+# two frames in flight use four busy streams (two contexts x {main, side}) beside torch's and
+# RCCL's.  Must be set before the HIP runtime initialises (measured: 148.1 -> 141.7 ms per frame).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 GATHER_CEILING_GBPS = 14600.0
@@ -92,6 +100,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--async-steps", action="store_true", help="N=1: enqueue the timed steps without host synchronisation, as N>1 always does")
     ap.add_argument("--cpu-sample-tiles", type=int, default=384)
+    ap.add_argument("--no-two-in-flight", action="store_true", help="N=1: skip the extra two-contexts-in-flight measurement")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="asynchronous steps alternate between this many contexts/streams (default: 2 for N>1, 1 for N=1); "
+                         "the latency tail of step k then overlaps the bulk of step k+1")
     args = ap.parse_args()
 
     import torch
@@ -124,7 +136,7 @@ def main():
     if args.batch_paths:
         opts["batch_paths"] = args.batch_paths
     ctx = yk.Context(local_rank, **opts)
-    scene = yk.Scene(ctx, sd)
+    scene = yk.Scene(ctx, sd)  # one device copy, rendered by every context of this rank
     info = scene.info()
     fs = yk.FilmSettings(res=wl["res"], tile_dim=16)
     cam = yk.Camera(sd.camera, fs)
@@ -151,17 +163,37 @@ def main():
     # enqueued on torch's current stream and nothing waits on the host inside the timed region;
     # ray counts are taken from one synchronous step beforehand (every step renders the same frame).
     async_steps = world > 1 or args.async_steps
+    # Asynchronous steps alternate between `in_flight` slots — a context (work buffers, HIP
+    # streams), a torch stream, a slab and gather buffers each — so that the latency tail of step k
+    # (late bounces: few rays, every launch as long as its longest ray) runs beside the bulk of
+    # step k+1.  Every slot renders the same scene copy and tile list; steps stay ordered per slot.
+    in_flight = max(1, args.frames_in_flight or (2 if world > 1 else 1)) if async_steps else 1
+    slots = [dict(ctx=ctx, it=it, slab=slab, gathered=gathered, film=film, stream=None)]
+    for _ in range(1, in_flight):
+        c2 = yk.Context(local_rank, **opts)
+        slots.append(dict(ctx=c2, it=yk.IntegratorType.instantiate(c2, integ), slab=torch.zeros_like(slab),
+                          gathered=[torch.zeros_like(slab) for _ in range(world)] if gathered is not None else None,
+                          film=torch.zeros_like(film) if film is not None else None, stream=torch.cuda.Stream(dev)))
+    step_no = [0]
 
     def step(want_stats=True):
+        sl = slots[step_no[0] % in_flight]
+        step_no[0] += 1
+        if sl["stream"] is not None:
+            with torch.cuda.stream(sl["stream"]):
+                return step_on(sl, want_stats)
+        return step_on(sl, want_stats)
+
+    def step_on(sl, want_stats):
         cs = torch.cuda.current_stream().cuda_stream if async_steps else None
-        st = it.render_tile_list_device(scene, cam, sampler, my_list, slab.data_ptr(), stream=cs, want_stats=want_stats)
+        st = sl["it"].render_tile_list_device(scene, cam, sampler, my_list, sl["slab"].data_ptr(), stream=cs, want_stats=want_stats)
         if world > 1:
-            dist.gather(slab, gathered, dst=0)  # RCCL, same stream
+            dist.gather(sl["slab"], sl["gathered"], dst=0)  # RCCL, ordered after the render on this slot's stream
             if rank == 0:
                 for r in range(world):
-                    rank_lists[r].update_film_device(gathered[r].data_ptr(), wl["res"], film.data_ptr(), stream=cs)
+                    rank_lists[r].update_film_device(sl["gathered"][r].data_ptr(), wl["res"], sl["film"].data_ptr(), stream=cs)
         else:
-            my_list.update_film_device(slab.data_ptr(), wl["res"], film.data_ptr(), stream=cs)
+            my_list.update_film_device(sl["slab"].data_ptr(), wl["res"], sl["film"].data_ptr(), stream=cs)
         return st
 
     def sync():
@@ -170,9 +202,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if in_flight > 1:  # setup: every slot allocates its work buffers on its first step
+        sync()
+        for _ in range(in_flight):
+            step()
+            sync()
     for _ in range(args.warmup):
         step()
-    probe = step() if async_steps else None  # untimed: per-step ray counts and kernel timings for the asynchronous mode
+    sync()
+    probe = step() if async_steps else None  # untimed, alone on the GPU: per-step ray counts and kernel timings for the asynchronous mode
     sync()
     t0 = time.perf_counter()
     rays = shadow = 0
@@ -200,8 +238,39 @@ def main():
     else:
         rays_all, shadow_all = rays, shadow
 
+    # N = 1, synchronous default: also time the same K steps enqueued asynchronously on two
+    # contexts — what N > 1 does by default — so that the scaling figures have a like-for-like base.
+    two_in_flight = None
+    if world == 1 and in_flight == 1 and not args.no_two_in_flight:
+        c2 = yk.Context(local_rank, **opts)
+        pair = [(it, slab, film, torch.cuda.Stream(dev)),
+                (yk.IntegratorType.instantiate(c2, integ), torch.zeros_like(slab), torch.zeros_like(film), torch.cuda.Stream(dev))]
+
+        def enqueue(i):
+            it_, slab_, film_, st_ = pair[i % 2]
+            it_.render_tile_list_device(scene, cam, sampler, my_list, slab_.data_ptr(), stream=st_.cuda_stream, want_stats=False)
+            my_list.update_film_device(slab_.data_ptr(), wl["res"], film_.data_ptr(), stream=st_.cuda_stream)
+
+        torch.cuda.synchronize()
+        for i in range(2):
+            enqueue(i)
+            torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for i in range(args.steps):
+            enqueue(i)
+        torch.cuda.synchronize()
+        tp = time.perf_counter() - tp
+        if not torch.equal(pair[1][2], film):
+            raise SystemExit("[bench] films of the two contexts differ")
+        two_in_flight = {"value": rays_all / tp * 1e-6, "ms_per_step": tp / args.steps * 1e3,
+                         "note": "same K steps, enqueued without host sync alternately on two contexts/streams (the N>1 default)"}
+        c2.close()
+
     if rank == 0:
         film_mean = film.view(-1, 3).mean(dim=0).tolist()
+        for sl in slots[1:]:
+            if not torch.equal(sl["film"], film):
+                raise SystemExit("[bench] films of the slots in flight differ")
         value = rays_all / elapsed * 1e-6
         cpu = None
         counters = None
@@ -260,19 +329,21 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl["desc"], "triangles": sd.n_triangles, "spp": spp, "max_depth": wl["depth"], "tiles": int(len(tiles)),
-                       "partition": f"spiral tiles dealt round-robin to {world} rank(s), RCCL gather to rank 0" if world > 1 else "single GPU"},
+                       "partition": f"spiral tiles dealt round-robin to {world} rank(s), RCCL gather to rank 0" if world > 1 else "single GPU",
+                       "frames_in_flight": in_flight},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "extra": {"rays_per_step": rays_all // args.steps, "shadow_rays_per_step": shadow_all // args.steps,
                       "shadow_Mray_per_s": shadow_all / elapsed * 1e-6, "rank0_device_s_per_step": t_dev / args.steps,
                       "rank0_trace_s": t_trace / args.steps, "rank0_shadow_s": t_shadow / args.steps, "rank0_shade_s": t_shade / args.steps,
-                      "film_mean_rgb": film_mean, "bvh_build_s": info.build_seconds, "scene_upload_s": info.upload_seconds,
+                      "two_in_flight": two_in_flight, "film_mean_rgb": film_mean, "bvh_build_s": info.build_seconds, "scene_upload_s": info.upload_seconds,
                       "steps_mode": "asynchronous (no host sync inside the timed region; per-kernel times and ray counts from one untimed probe step)" if async_steps
                       else "synchronous (per-kernel HIP-event times read after every step of the timed region)"},
         }
         print(json.dumps(out), flush=True)
     scene.close()
-    ctx.close()
+    for sl in slots:
+        sl["ctx"].close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -240,7 +240,11 @@ yk_status yk_film_update_tiles(const yk_tile* tiles, size_t n_tiles, const float
 
 /* ---- scene ------------------------------------------------------------------ */
 /* BoundingVolumeHierarchy::new (bvh.rs:39-115) on the host, then upload.
- * ctx may be NULL: host-only scene (BVH build/export without a GPU). */
+ * ctx may be NULL: host-only scene (BVH build/export without a GPU).
+ * A scene (and a yk_tile_list) is read-only after creation and belongs to the DEVICE of `ctx`:
+ * any context on that device may render it, also concurrently from several threads — two
+ * contexts with their own streams keep two renders in flight, so the latency tail of one
+ * overlaps the bulk of the next. */
 yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* desc, yk_scene** out);
 void yk_scene_destroy(yk_scene* scene);
 yk_status yk_scene_get_info(const yk_scene* scene, yk_scene_info* out);

@@ -263,6 +263,41 @@ def test_render_from_worker_threads(ctx, yk):
     assert np.array_equal(_bits(out), _bits(ref))
 
 
+def test_one_scene_rendered_by_two_contexts_at_once(ctx, yk):
+    """A scene and a tile list belong to the device: a second context renders them too, and two
+    contexts keep two renders in flight (bench.py --frames-in-flight 2).  Both
+    threads get the pixels of a plain single-context render."""
+    import threading
+
+    sd = scenes.by_name("city-tiny")
+    sc = yk.Scene(ctx, sd)
+    fs = yk.FilmSettings(res=(160, 96))
+    cam = yk.Camera(sd.camera, fs)
+    tiles = yk.film_tiles(fs)
+    smp = yk.SamplerType.Stratified((2, 2), True, SEED)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=6))
+    ref, ref_stats = yk.IntegratorType.instantiate(ctx, integ).render_tiles(sc, cam, smp, tiles)
+    ctx2 = yk.Context(0)
+    outs, errs = {}, []
+
+    def worker(k, c):
+        try:
+            it = yk.IntegratorType.instantiate(c, integ)
+            for _ in range(4):
+                px, st = it.render_tiles(sc, cam, smp, tiles)
+                assert st.rays == ref_stats.rays
+            outs[k] = px
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(k, c)) for k, c in enumerate((ctx, ctx2))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert np.array_equal(_bits(outs[0]), _bits(ref)) and np.array_equal(_bits(outs[1]), _bits(ref))
+    ctx2.close()
+
+
 def test_render_one_tile_accumulating(ctx, yk, oracle):
     """Integrator::render(accumulating=true) through the one-tile entry point."""
     sd = scenes.by_name("city-tiny")

@@ -916,22 +916,19 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         // otherwise everything goes to the first queue and one launch traces it
         const bool split = packet_shadow && scene->n_lights > scene->n_delta_lights;
         const bool all_delta = packet_shadow && !split;  // no area lights: the single queue is all coherent
+        unsigned* bc = ctrl + YK_CTRL_BOUNCE(b);  // this bounce's counters and queue heads, zeroed with the batch
         int e = kt.begin(st);
         if (packet)
-            launch_trace_closest_packet(st, pg, ds, pc.rayO, pc.rayD, ctrl + cur, ctrl + YK_CTRL_HEADS + 3 * b, ws.hit.as<int>(), counters);
+            launch_trace_closest_packet(st, pg, ds, pc.rayO, pc.rayD, bc, bc + YK_CTRL_HEAD, ws.hit.as<int>(), counters);
         else
-            launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, ctrl + cur, ctrl + YK_CTRL_HEADS + 3 * b, ws.hit.as<int>(), nullptr, nullptr,
+            launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, bc, bc + YK_CTRL_HEAD, ws.hit.as<int>(), nullptr, nullptr,
                                  ws.spill.as<uint2>(), tg * trace_block_size(), ctrl, counters);
         kt.end(e, 0, st);
         if (overlap && b > 0) (void)hipStreamWaitEvent(st, ws.ev_acc, 0);
-        // reset the consumer-side counters of this bounce
-        (void)hipMemsetAsync(ctrl + (cur ^ 1u), 0, 4, st);
-        (void)hipMemsetAsync(ctrl + YK_CTRL_SHQ, 0, 4, st);
-        (void)hipMemsetAsync(ctrl + YK_CTRL_SHQ2, 0, 4, st);
         e = kt.begin(st);
         launch_shade(st, sg, ds, prm, pixel_xy, sample_index_tab, pc, pn, ws.hit.as<int>(), ws.pend.as<float4>(), ws.shO.as<float4>(),
                      ws.shD.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ws.shq.as<unsigned>(), ws.shO2.as<float4>(),
-                     ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), ctrl, cur, split ? 1u : 0u, (b > 0 && ctx->shade_reorder) ? 1u : 0u);
+                     ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc, split ? 1u : 0u, (b > 0 && ctx->shade_reorder) ? 1u : 0u);
         kt.end(e, 2, st);
         if (overlap) {
             (void)hipEventRecord(ws.ev_shade, st);
@@ -940,33 +937,31 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         e = kt.begin(sb);
         uint2* any_spill = (overlap ? ws.spill_side : ws.spill).as<uint2>();
         if (all_delta) {
-            launch_trace_any_packet(sb, pg, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), ctrl + YK_CTRL_SHQ,
-                                    ctrl + YK_CTRL_HEADS + 3 * b + 1, ws.vis.as<unsigned char>(), counters + 1);
+            launch_trace_any_packet(sb, pg, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), bc + YK_CTRL_SHQ,
+                                    bc + YK_CTRL_HEAD + 1, ws.vis.as<unsigned char>(), counters + 1);
         } else {
-            launch_trace_any(sb, tg, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), ctrl + YK_CTRL_SHQ,
-                             ctrl + YK_CTRL_HEADS + 3 * b + 1, ws.vis.as<unsigned char>(), any_spill, tg * trace_block_size(), ctrl, counters + 1);
+            launch_trace_any(sb, tg, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), bc + YK_CTRL_SHQ,
+                             bc + YK_CTRL_HEAD + 1, ws.vis.as<unsigned char>(), any_spill, tg * trace_block_size(), ctrl, counters + 1);
             if (split && n_shadow_launches) ++*n_shadow_launches;
             if (split)  // rays converging on a point / spot / distant light: wave packets
-                launch_trace_any_packet(sb, pg, ds, ws.shO2.as<float4>(), ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), ctrl + YK_CTRL_SHQ2,
-                                        ctrl + YK_CTRL_HEADS + 3 * b + 2, ws.vis.as<unsigned char>(), counters + 1);
+                launch_trace_any_packet(sb, pg, ds, ws.shO2.as<float4>(), ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc + YK_CTRL_SHQ2,
+                                        bc + YK_CTRL_HEAD + 2, ws.vis.as<unsigned char>(), counters + 1);
         }
         kt.end(e, 1, sb);
         if (n_shadow_launches) ++*n_shadow_launches;
-        launch_accumulate(sb, sg, prm, pc, ws.pend.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ds.n_lights, sample_buf, ctrl, cur);
+        launch_accumulate(sb, sg, prm, pc, ws.pend.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ds.n_lights, sample_buf, bc);
         if (overlap) (void)hipEventRecord(ws.ev_acc, sb);
         if (kt.on && std::getenv("YK_DEBUG_BOUNCES")) {  // per-bounce breakdown (synchronises; diagnostics only)
-            unsigned h[4];
+            unsigned h[YK_CTRL_STRIDE + 1];
             (void)hipStreamSynchronize(st);
             (void)hipStreamSynchronize(sb);
-            (void)hipMemcpy(h, ctrl, 16, hipMemcpyDeviceToHost);
-            unsigned hq2 = 0;
-            (void)hipMemcpy(&hq2, ctrl + YK_CTRL_SHQ2, 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h, bc, sizeof(h), hipMemcpyDeviceToHost);
             float tt = 0, ts = 0, th = 0;
             (void)hipEventElapsedTime(&tt, ctx->ev_pool[kt.spans[0].back().first], ctx->ev_pool[kt.spans[0].back().second]);
             (void)hipEventElapsedTime(&ts, ctx->ev_pool[kt.spans[1].back().first], ctx->ev_pool[kt.spans[1].back().second]);
             (void)hipEventElapsedTime(&th, ctx->ev_pool[kt.spans[2].back().first], ctx->ev_pool[kt.spans[2].back().second]);
-            std::fprintf(stderr, "bounce %u: rays %u trace %.3f ms (%.0f Mray/s) | shadow rays %u %.3f ms (%.0f Mray/s) | shade %.3f ms | survivors %u\n", b, h[cur],
-                         tt, h[cur] / (tt * 1e3), h[YK_CTRL_SHQ] + hq2, ts, (h[YK_CTRL_SHQ] + hq2) / (ts * 1e3), th, h[cur ^ 1u]);
+            std::fprintf(stderr, "bounce %u: rays %u trace %.3f ms (%.0f Mray/s) | shadow rays %u %.3f ms (%.0f Mray/s) | shade %.3f ms | survivors %u\n", b, h[0],
+                         tt, h[0] / (tt * 1e3), h[YK_CTRL_SHQ] + h[YK_CTRL_SHQ2], ts, (h[YK_CTRL_SHQ] + h[YK_CTRL_SHQ2]) / (ts * 1e3), th, h[YK_CTRL_STRIDE]);
         }
         cur ^= 1u;
     }
@@ -985,17 +980,17 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (prepared) {
-        if (prepared->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "tile list was not created on this context");
+        if (prepared->device != ctx->device) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "tile list was not created on this context's device");
         tiles = prepared->tiles.data();
         tile_samples = prepared->samples.empty() ? nullptr : prepared->samples.data();
         n_tiles = prepared->tiles.size();
     }
     if (!scene || !camera || !tiles || n_tiles == 0 || !d_out_rgb) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
-    if (!scene->on_device || scene->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context");
+    if (!scene->on_device || scene->device != ctx->device) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context's device");
     RenderParams prm;
     yk_status ps = make_params(ctx, sampler, integrator, prm);
     if (ps != YK_OK) return ps;
-    if (prm.integrator == YK_INTEGRATOR_PATH && prm.max_depth > (YK_CTRL_WORDS - YK_CTRL_HEADS) / 3)
+    if (prm.integrator == YK_INTEGRATOR_PATH && prm.max_depth > YK_CTRL_MAX_DEPTH)
         return fail(ctx, YK_ERR_INVALID_ARGUMENT, "max_depth too large");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
@@ -1118,7 +1113,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
             unsigned* ctrl = ws.ctrl.as<unsigned>();
             const uint32_t n = (uint32_t)std::min<uint64_t>(batch, work - w0);
             HIP_TRY(ctx, hipMemsetAsync(ctrl, 0, YK_CTRL_WORDS * 4, bs));
-            launch_raygen(bs, cam, prm, pixel_xy, pixel_sample, w0, n, path_buffers(ws, 0), sample_buf, ctrl);
+            launch_raygen(bs, cam, prm, pixel_xy, pixel_sample, w0, n, path_buffers(ws, 0), sample_buf, ctrl + YK_CTRL_BOUNCE(0));
             ++n_batches;
             if (is_path) {
                 run_bounces(ctx, ws, bs, scene, prm, pixel_xy, pixel_sample, sample_buf, kt, counters, true, &n_shadow);
@@ -1127,7 +1122,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
                 PathBuffers pc = path_buffers(ws, 0);
                 const bool want_stats = prm.integrator == YK_INTEGRATOR_BVH_INTERSECTIONS;
                 int e = kt.begin(bs);
-                launch_trace_closest(bs, trace_grid(ctx), scene->dev, pc.rayO, pc.rayD, nullptr, ctrl, ctrl + YK_CTRL_HEADS, ws.hit.as<int>(), nullptr,
+                launch_trace_closest(bs, trace_grid(ctx), scene->dev, pc.rayO, pc.rayD, nullptr, ctrl + YK_CTRL_BOUNCE(0), ctrl + YK_CTRL_BOUNCE(0) + YK_CTRL_HEAD, ws.hit.as<int>(), nullptr,
                                      want_stats ? ctx->stats4.as<uint4>() : nullptr, ws.spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), ctrl,
                                      counters);
                 kt.end(e, 0, bs);
@@ -1284,7 +1279,7 @@ yk_status yk_film_update_tile_list_device(yk_context* ctx, const yk_tile_list* l
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (!list || !d_tile_rgb || !d_film_rgb) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
-    if (list->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "tile list was not created on this context");
+    if (list->device != ctx->device) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "tile list was not created on this context's device");
     for (const yk_tile& t : list->tiles)
         if (t.x1 > res_x || t.y1 > res_y) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "update_tile: Tile doesn't fit film");
     (void)hipSetDevice(ctx->device);
@@ -1391,13 +1386,13 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (!scene || !ray_o || !ray_d || !pixel_xy || !sample_index || !out_li || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
-    if (!scene->on_device || scene->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context");
+    if (!scene->on_device || scene->device != ctx->device) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context's device");
     if (n > ((size_t)1 << 28)) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many rays");
     RenderParams prm;
     yk_status ps = make_params(ctx, sampler, integrator, prm);
     if (ps != YK_OK) return ps;
     if (prm.integrator != YK_INTEGRATOR_PATH) return fail(ctx, YK_ERR_UNSUPPORTED, "yk_li implements the Path integrator");
-    if (prm.max_depth > (YK_CTRL_WORDS - YK_CTRL_HEADS) / 3) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "max_depth too large");
+    if (prm.max_depth > YK_CTRL_MAX_DEPTH) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "max_depth too large");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     yk_status wb = ensure_work_buffers(ctx, ctx->ws[0], n, scene->n_lights, scene->n_delta_lights);
@@ -1418,7 +1413,7 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
     HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64, st));
     HIP_TRY(ctx, hipMemsetAsync(ctrl, 0, YK_CTRL_WORDS * 4, st));
     launch_raygen_user(st, prm, ctx->scratch[4].as<float>(), ctx->scratch[5].as<float>(), ctx->scratch[6].as<uint16_t>(), ctx->scratch[7].as<uint32_t>(),
-                       dimension, (uint32_t)n, path_buffers(ctx->ws[0], 0), ctx->sample_buf.as<float4>(), ctx->pixel_xy.as<uint32_t>(), ctrl);
+                       dimension, (uint32_t)n, path_buffers(ctx->ws[0], 0), ctx->sample_buf.as<float4>(), ctx->pixel_xy.as<uint32_t>(), ctrl + YK_CTRL_BOUNCE(0));
     KernelTimer kt;
     kt.ctx = ctx;
     kt.on = false;
@@ -1443,7 +1438,7 @@ yk_status yk_trace_closest(yk_context* ctx, const yk_scene* scene, size_t n, con
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (!scene || !ray_o || !ray_d || !out_shape || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
-    if (!scene->on_device || scene->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context");
+    if (!scene->on_device || scene->device != ctx->device) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context's device");
     if (n > 0xFFFFFF00ull) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many rays");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
@@ -1504,7 +1499,7 @@ yk_status yk_trace_any(yk_context* ctx, const yk_scene* scene, size_t n, const f
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (!scene || !ray_o || !ray_d || !t_max || !out_hit || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
-    if (!scene->on_device || scene->ctx != ctx) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context");
+    if (!scene->on_device || scene->device != ctx->device) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene was not created on this context's device");
     if (n > 0xFFFFFF00ull) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many rays");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;

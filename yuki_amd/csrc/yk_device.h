@@ -137,13 +137,20 @@ struct PathBuffers {
     uint4* rngs;
 };
 
-// control block, zeroed per batch: [0..1] active counts (ping-pong), [2] and [4] shadow queue
-// lengths (area / delta lights), [3] error flags, [8+k] work-queue heads of the k-th launch
-#define YK_CTRL_WORDS 256
-#define YK_CTRL_SHQ 2   // shadow rays towards area lights (scattered directions)
-#define YK_CTRL_SHQ2 4  // shadow rays towards point / spot / distant lights (one target: coherent)
+// control block, zeroed ONCE per batch (no per-bounce resets: every bounce has its own words):
+// [3] error flags; bounce b owns the 8 words at YK_CTRL_BOUNCE(b): +0 paths entering the bounce
+// (written by raygen / by shade of bounce b-1), +1 / +2 shadow queue lengths (area / delta
+// lights), +3..5 work-queue heads of its closest-hit and any-hit launches.  The per-stage entry
+// points (yk_trace_closest / yk_trace_any) use word 0 as the ray count and YK_CTRL_HEADS as head.
+#define YK_CTRL_WORDS 1024
 #define YK_CTRL_ERR 3
 #define YK_CTRL_HEADS 8
+#define YK_CTRL_STRIDE 8
+#define YK_CTRL_BOUNCE(b) (8 + YK_CTRL_STRIDE * (b))
+#define YK_CTRL_SHQ 1   // shadow rays towards area lights (scattered directions)
+#define YK_CTRL_SHQ2 2  // shadow rays towards point / spot / distant lights (one target: coherent)
+#define YK_CTRL_HEAD 3  // + {0: closest, 1: any, 2: any (delta queue)}
+#define YK_CTRL_MAX_DEPTH ((YK_CTRL_WORDS - 8) / YK_CTRL_STRIDE - 1)
 
 struct RenderParams {
     SamplerCfg sampler;

@@ -59,9 +59,9 @@ __device__ __forceinline__ void camera_ray(const DevCamera& cam, float fx, float
 // `pixel_sample` != null: the accumulating film (integrators/mod.rs:146-161) — ONE sample per
 // pixel whose global index is the tile's FilmTile.sample; otherwise all spp samples.
 __global__ void k_raygen(DevCamera cam, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* pixel_sample, uint64_t work0, uint32_t n,
-                         PathBuffers out, float4* sample_buf, unsigned* ctrl) {
+                         PathBuffers out, float4* sample_buf, unsigned* count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) ctrl[0] = n;
+    if (i == 0) *count = n;
     if (i >= n) return;
     uint64_t w = work0 + i;
     uint32_t spp = prm.sampler.spp;
@@ -89,9 +89,9 @@ __global__ void k_raygen(DevCamera cam, RenderParams prm, const uint32_t* pixel_
 
 // Integrator::li entry: caller-supplied rays (yk_li)
 __global__ void k_raygen_user(RenderParams prm, const float* ray_o, const float* ray_d, const uint16_t* pixel, const uint32_t* sample_index,
-                              uint32_t dimension, uint32_t n, PathBuffers out, float4* sample_buf, uint32_t* pixel_xy, unsigned* ctrl) {
+                              uint32_t dimension, uint32_t n, PathBuffers out, float4* sample_buf, uint32_t* pixel_xy, unsigned* count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) ctrl[0] = n;
+    if (i == 0) *count = n;
     if (i >= n) return;
     uint32_t px = pixel[2 * i], py = pixel[2 * i + 1];
     pixel_xy[i] = px | (py << 16);
@@ -150,12 +150,13 @@ template <int BLOCK, int CAP, int CAPQ>
 __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                                                  PathBuffers cur, PathBuffers nxt,
                                                  const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis,
-                                                 unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* ctrl, unsigned cur_slot, unsigned split_delta, unsigned reorder) {
+                                                 unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder) {
+    // `bc`: this bounce's words of the control block (yk_device.h); the next bounce's follow it
     __shared__ ShadeStaging<CAP, CAPQ> stg;
-    const unsigned n = ctrl[cur_slot];
+    const unsigned n = bc[0];
     const unsigned nl = sc.n_lights;
-    unsigned* next_count = ctrl + (cur_slot ^ 1u);
-    unsigned* shq_count = ctrl + YK_CTRL_SHQ;
+    unsigned* next_count = bc + YK_CTRL_STRIDE;
+    unsigned* shq_count = bc + YK_CTRL_SHQ;
     if (threadIdx.x == 0) {
         stg.fill_p = 0;
         stg.fill_q = 0;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
     // target and suit the wave-packet any-hit kernel.  The staging buffer only ever holds
     // rays of one class (it is flushed when the class of the light changes).
     auto flush_q = [&](unsigned fill, unsigned delta) {
-        if (threadIdx.x == 0) stg.gbase = atomicAdd(delta ? ctrl + YK_CTRL_SHQ2 : shq_count, fill);
+        if (threadIdx.x == 0) stg.gbase = atomicAdd(delta ? bc + YK_CTRL_SHQ2 : shq_count, fill);
         __syncthreads();
         const unsigned gb = stg.gbase;
         float4* dO = delta ? shO2 : shO;
@@ -405,8 +406,8 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
 // radiance = fold over lights (in light order) of the unoccluded contributions,
 // + beta*Le, clamp, then incoming_radiance += beta * radiance   (path.rs:102-129)
 __global__ void k_accumulate(RenderParams prm, PathBuffers cur, const float4* pend, const float4* shC, const unsigned char* vis, unsigned nl,
-                             float4* sample_buf, const unsigned* ctrl, unsigned cur_slot) {
-    const unsigned n = ctrl[cur_slot];
+                             float4* sample_buf, const unsigned* bc) {
+    const unsigned n = bc[0];
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 p = pend[i];
         unsigned kind = __float_as_uint(p.w);
@@ -604,13 +605,13 @@ void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, 
 void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                   PathBuffers cur, PathBuffers nxt,
                   const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis, unsigned* shq, float4* shO2,
-                  float4* shD2, unsigned* shq2, unsigned* ctrl, unsigned cur_slot, unsigned split_delta, unsigned reorder) {
+                  float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder) {
     hipLaunchKernelGGL((k_shade<256, SHADE_CAP, SHADE_CAPQ>), dim3(grid), dim3(256), 0, s, sc, prm, pixel_xy, sample_index_tab, cur, nxt, hit_tri, pend, shO, shD, shC, vis, shq,
-                       shO2, shD2, shq2, ctrl, cur_slot, split_delta, reorder);
+                       shO2, shD2, shq2, bc, split_delta, reorder);
 }
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
-                       const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* ctrl, unsigned cur_slot) {
-    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, prm, cur, pend, shC, vis, nl, sample_buf, ctrl, cur_slot);
+                       const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* bc) {
+    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, prm, cur, pend, shC, vis, nl, sample_buf, bc);
 }
 void launch_resolve(hipStream_t s, const float4* sample_buf, uint32_t n_pixels, uint32_t spp, float* out_rgb) {
     if (!n_pixels) return;
