@@ -160,7 +160,7 @@ def main():
     my_list = yk.TileList(ctx, my_tiles)
     rank_lists = [yk.TileList(ctx, ydist.shard_tiles(tiles, r, world)) for r in range(world)] if (rank == 0 and world > 1) else None
     # N > 1 (or --async-steps): every launch of a step — render, RCCL gather, film scatter — is
-    # enqueued on torch's current stream and nothing waits on the host inside the timed region;
+    # enqueued on one stream and nothing waits on the host inside the timed region;
     # ray counts are taken from one synchronous step beforehand (every step renders the same frame).
     async_steps = world > 1 or args.async_steps
     # Asynchronous steps alternate between `in_flight` slots — a context (work buffers, HIP
@@ -168,12 +168,17 @@ def main():
     # (late bounces: few rays, every launch as long as its longest ray) runs beside the bulk of
     # step k+1.  Every slot renders the same scene copy and tile list; steps stay ordered per slot.
     in_flight = max(1, args.frames_in_flight or (2 if world > 1 else 1)) if async_steps else 1
-    slots = [dict(ctx=ctx, it=it, slab=slab, gathered=gathered, film=film, stream=None)]
+    slots = [dict(ctx=ctx, it=it, slab=slab, gathered=gathered, film=film)]
     for _ in range(1, in_flight):
         c2 = yk.Context(local_rank, **opts)
         slots.append(dict(ctx=c2, it=yk.IntegratorType.instantiate(c2, integ), slab=torch.zeros_like(slab),
                           gathered=[torch.zeros_like(slab) for _ in range(world)] if gathered is not None else None,
-                          film=torch.zeros_like(film) if film is not None else None, stream=torch.cuda.Stream(dev)))
+                          film=torch.zeros_like(film) if film is not None else None))
+    # A slot's work — render, RCCL gather, film scatter — is ordered on its context's own stream
+    # (torch sees it as an ExternalStream): no further stream takes part, so the main / side stream
+    # pairs of the slots are the only busy streams (HIP shares hardware queues between streams).
+    for sl in slots:
+        sl["stream"] = torch.cuda.ExternalStream(sl["ctx"].stream_handle, device=dev) if async_steps else None
     step_no = [0]
 
     def step(want_stats=True):
@@ -185,15 +190,14 @@ def main():
         return step_on(sl, want_stats)
 
     def step_on(sl, want_stats):
-        cs = torch.cuda.current_stream().cuda_stream if async_steps else None
-        st = sl["it"].render_tile_list_device(scene, cam, sampler, my_list, sl["slab"].data_ptr(), stream=cs, want_stats=want_stats)
+        st = sl["it"].render_tile_list_device(scene, cam, sampler, my_list, sl["slab"].data_ptr(), stream=None, want_stats=want_stats)
         if world > 1:
-            dist.gather(sl["slab"], sl["gathered"], dst=0)  # RCCL, ordered after the render on this slot's stream
+            dist.gather(sl["slab"], sl["gathered"], dst=0)  # RCCL, ordered after the render through torch's current stream = the slot's
             if rank == 0:
                 for r in range(world):
-                    rank_lists[r].update_film_device(sl["gathered"][r].data_ptr(), wl["res"], sl["film"].data_ptr(), stream=cs)
+                    rank_lists[r].update_film_device(sl["gathered"][r].data_ptr(), wl["res"], sl["film"].data_ptr(), ctx=sl["ctx"])
         else:
-            my_list.update_film_device(sl["slab"].data_ptr(), wl["res"], sl["film"].data_ptr(), stream=cs)
+            my_list.update_film_device(sl["slab"].data_ptr(), wl["res"], sl["film"].data_ptr(), ctx=sl["ctx"])
         return st
 
     def sync():
@@ -243,13 +247,12 @@ def main():
     two_in_flight = None
     if world == 1 and in_flight == 1 and not args.no_two_in_flight:
         c2 = yk.Context(local_rank, **opts)
-        pair = [(it, slab, film, torch.cuda.Stream(dev)),
-                (yk.IntegratorType.instantiate(c2, integ), torch.zeros_like(slab), torch.zeros_like(film), torch.cuda.Stream(dev))]
+        pair = [(ctx, it, slab, film), (c2, yk.IntegratorType.instantiate(c2, integ), torch.zeros_like(slab), torch.zeros_like(film))]
 
-        def enqueue(i):
-            it_, slab_, film_, st_ = pair[i % 2]
-            it_.render_tile_list_device(scene, cam, sampler, my_list, slab_.data_ptr(), stream=st_.cuda_stream, want_stats=False)
-            my_list.update_film_device(slab_.data_ptr(), wl["res"], film_.data_ptr(), stream=st_.cuda_stream)
+        def enqueue(i):  # everything of a step on its context's own stream
+            c_, it_, slab_, film_ = pair[i % 2]
+            it_.render_tile_list_device(scene, cam, sampler, my_list, slab_.data_ptr(), stream=None, want_stats=False)
+            my_list.update_film_device(slab_.data_ptr(), wl["res"], film_.data_ptr(), ctx=c_)
 
         torch.cuda.synchronize()
         for i in range(2):
@@ -260,7 +263,7 @@ def main():
             enqueue(i)
         torch.cuda.synchronize()
         tp = time.perf_counter() - tp
-        if not torch.equal(pair[1][2], film):
+        if not torch.equal(pair[1][3], film):
             raise SystemExit("[bench] films of the two contexts differ")
         two_in_flight = {"value": rays_all / tp * 1e-6, "ms_per_step": tp / args.steps * 1e3,
                          "note": "same K steps, enqueued without host sync alternately on two contexts/streams (the N>1 default)"}

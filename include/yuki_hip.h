@@ -212,6 +212,12 @@ const char* yk_status_string(yk_status s);
 yk_status yk_context_create(int device, yk_context** out);
 void yk_context_destroy(yk_context* ctx);
 yk_status yk_last_error(const yk_context* ctx, char* buf, size_t cap);
+/* The hipStream_t every entry point of this context runs on when it is given no stream of the
+ * caller's (a render also uses a side stream that joins it again before the call's last launch).
+ * Lets a caller order its own device work — a collective, a film read-back — after a render
+ * without a second stream: wrap the handle (torch.cuda.ExternalStream, hipStreamWaitEvent ...).
+ * Owned by the context; NULL for a NULL context. */
+void* yk_context_stream(const yk_context* ctx);
 /* tuning knobs (none changes any result): "batch_paths" (camera samples per batch),
  * "streams" (1|2 work sets), "sample_buf_cap" (bytes), "time_kernels" (0|1),
  * "packet_bounces" / "packet_shadow_bounces" (leading bounces traced by the wave-packet

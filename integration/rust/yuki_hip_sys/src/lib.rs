@@ -218,6 +218,7 @@ extern "C" {
     pub fn yk_context_create(device: c_int, out: *mut *mut yk_context) -> yk_status;
     pub fn yk_context_destroy(ctx: *mut yk_context);
     pub fn yk_last_error(ctx: *const yk_context, buf: *mut c_char, cap: usize) -> yk_status;
+    pub fn yk_context_stream(ctx: *const yk_context) -> *mut c_void;
     pub fn yk_context_set_option(ctx: *mut yk_context, key: *const c_char, value: i64) -> yk_status;
     pub fn yk_camera_init(params: *const yk_camera_params, out: *mut yk_camera) -> yk_status;
     pub fn yk_film_tiles(res_x: u16, res_y: u16, tile_dim: u16, out: *mut yk_tile, cap: usize) -> usize;

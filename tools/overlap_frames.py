@@ -22,7 +22,7 @@ for i in range(2):
     it = yk.IntegratorType.instantiate(ctx, yk.IntegratorType.Path(yk.PathParams(max_depth=8)))
     tl = yk.TileList(ctx, mine)
     slab = torch.zeros(ydist.slab_pixels(tiles, G) * 3, dtype=torch.float32, device=dev)
-    sets.append((ctx, sc, cam, it, tl, slab, torch.cuda.Stream(dev)))
+    sets.append((ctx, sc, cam, it, tl, slab, torch.cuda.Stream(dev) if "torchstreams" in sys.argv else None))
 
 def run(n_sets):
     for rep in range(3):
@@ -30,7 +30,9 @@ def run(n_sets):
         t0 = time.perf_counter()
         for k in range(K):
             ctx, sc, cam, it, tl, slab, s = sets[k % n_sets]
-            it.render_tile_list_device(sc, cam, smp, tl, slab.data_ptr(), stream=s.cuda_stream, want_stats=False)
+            it.render_tile_list_device(sc, cam, smp, tl, slab.data_ptr(), stream=s.cuda_stream if s else None, want_stats=False)
+            if "sync" in sys.argv:
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     return dt / K * 1e3

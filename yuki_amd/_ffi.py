@@ -74,6 +74,7 @@ SYMBOLS = {
     "yk_context_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "yk_context_destroy": (None, [vp]),
     "yk_last_error": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
+    "yk_context_stream": (vp, [vp]),
     "yk_context_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
     "yk_camera_init": (C.c_int, [C.POINTER(abi.CameraParams), C.POINTER(abi.CameraMatrices)]),
     "yk_film_tiles": (C.c_size_t, [C.c_uint16, C.c_uint16, C.c_uint16, vp, C.c_size_t]),

@@ -104,9 +104,11 @@ class TileList:
         self.h = h
         self.n_pixels = int(((self.tiles["x1"].astype(np.int64) - self.tiles["x0"]) * (self.tiles["y1"].astype(np.int64) - self.tiles["y0"])).sum())
 
-    def update_film_device(self, d_tile_rgb_ptr, res, d_film_ptr, stream=None, accumulate=False):
-        """Film::update_tile for the whole list, device to device, enqueued on `stream`."""
-        check(lib().yk_film_update_tile_list_device(self.ctx.h, self.h, C.c_void_p(d_tile_rgb_ptr), res[0], res[1], C.c_void_p(d_film_ptr), C.c_void_p(stream) if stream else None, 1 if accumulate else 0), self.ctx.h)
+    def update_film_device(self, d_tile_rgb_ptr, res, d_film_ptr, stream=None, accumulate=False, ctx=None):
+        """Film::update_tile for the whole list, device to device, enqueued on `stream` (default:
+        the stream of `ctx`, any context on the list's device; default the one that made it)."""
+        c = ctx or self.ctx
+        check(lib().yk_film_update_tile_list_device(c.h, self.h, C.c_void_p(d_tile_rgb_ptr), res[0], res[1], C.c_void_p(d_film_ptr), C.c_void_p(stream) if stream else None, 1 if accumulate else 0), c.h)
 
     def close(self):
         if getattr(self, "h", None):
@@ -211,6 +213,12 @@ class Context:
 
     def set_option(self, key, value):
         check(lib().yk_context_set_option(self.h, key.encode(), int(value)), self.h)
+
+    @property
+    def stream_handle(self):
+        """The context's hipStream_t as an integer (yk_context_stream): wrap it, e.g. with
+        torch.cuda.ExternalStream, to order other device work after a render."""
+        return int(lib().yk_context_stream(self.h) or 0)
 
     def close(self):
         if getattr(self, "h", None):

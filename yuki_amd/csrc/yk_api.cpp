@@ -74,6 +74,7 @@ struct yk_context {
     } ws[2];
     DevBuf sample_buf, pixel_xy, tiles, tile_off, counters, stats4, hit4, scratch[8];
     std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;  // hand-over between a caller's stream and the context's own
     // every entry point that touches the context's buffers or streams holds this: calls on one
     // context from several host threads (the reference's tile workers) are serialised
     std::recursive_mutex mu;
@@ -161,12 +162,15 @@ yk_status yk_context_create(int device, yk_context** out) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    // Two streams per context (main + side); the second work set's pair is created on first use.
+    // HIP multiplexes streams onto few hardware queues (GPU_MAX_HW_QUEUES, default 4) and streams
+    // that share a queue serialise, so a context never holds streams it does not run work on.
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->ws[1].stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ws[0].done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ws[1].done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_out, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->ws[0].side, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->ws[1].side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ws[0].ev_shade, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ws[1].ev_shade, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ws[0].ev_acc, hipEventDisableTiming) != hipSuccess ||
@@ -187,7 +191,7 @@ void yk_context_destroy(yk_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->ws[1].stream);
+    if (ctx->ws[1].stream) (void)hipStreamSynchronize(ctx->ws[1].stream);
     for (WorkSet& w : ctx->ws) {
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 4; ++b) w.path[a][b].release();
@@ -201,7 +205,9 @@ void yk_context_destroy(yk_context* ctx) {
             (void)hipStreamDestroy(w.side);
         }
     }
-    (void)hipStreamDestroy(ctx->ws[1].stream);
+    if (ctx->ws[1].stream) (void)hipStreamDestroy(ctx->ws[1].stream);
+    if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
+    if (ctx->ev_out) (void)hipEventDestroy(ctx->ev_out);
     DevBuf* all[] = {&ctx->sample_buf, &ctx->pixel_xy, &ctx->tiles, &ctx->tile_off, &ctx->counters, &ctx->stats4, &ctx->hit4};
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : ctx->scratch) b.release();
@@ -215,6 +221,8 @@ yk_status yk_last_error(const yk_context* ctx, char* buf, size_t cap) {
     std::snprintf(buf, cap, "%s", ctx->last_error.c_str());
     return YK_OK;
 }
+
+void* yk_context_stream(const yk_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 yk_status yk_context_set_option(yk_context* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return YK_ERR_INVALID_ARGUMENT;
@@ -993,7 +1001,23 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
     if (prm.integrator == YK_INTEGRATOR_PATH && prm.max_depth > YK_CTRL_MAX_DEPTH)
         return fail(ctx, YK_ERR_INVALID_ARGUMENT, "max_depth too large");
     (void)hipSetDevice(ctx->device);
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    // The render always runs on the context's own streams; a caller's stream hands over to them
+    // and takes over again at the end (two event waits), so the work is ordered on it as if it
+    // had been launched there — and the main / side stream pair keeps its own hardware queues.
+    hipStream_t caller = (hipStream_t)stream;
+    hipStream_t st = ctx->stream;
+    if (caller) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_in, caller));
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_in, 0));
+    }
+    struct HandBack {  // on every exit path: whatever was enqueued is ordered before the caller's next work
+        yk_context* c;
+        hipStream_t caller, st;
+        ~HandBack() {
+            if (!caller) return;
+            if (hipEventRecord(c->ev_out, st) == hipSuccess) (void)hipStreamWaitEvent(caller, c->ev_out, 0);
+        }
+    } hand_back{ctx, caller, st};
 
     // tiles -> pixel ranges (assert!(tile_pixels.len() >= tile.bb.area()), integrators/mod.rs:131)
     std::vector<uint32_t> off(n_tiles + 1, 0);
@@ -1031,6 +1055,10 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
             const size_t fit = (free_b / 2) / per_path;
             if (fit >= 65536 && batch > fit) batch = fit;
         }
+    }
+    if (n_ws == 2 && !ctx->ws[1].stream) {  // the second work set's stream pair, on first use
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->ws[1].stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->ws[1].side, hipStreamNonBlocking));
     }
     for (int w = 0; w < n_ws; ++w) {
         yk_status wb = ensure_work_buffers(ctx, ctx->ws[w], batch, scene->n_lights, scene->n_delta_lights);
