@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--async-steps", action="store_true", help="N=1: enqueue the timed steps without host synchronisation, as N>1 always does")
     ap.add_argument("--cpu-sample-tiles", type=int, default=384)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N>1 rehearsal on a single GPU: every rank uses cuda:0 and the gather goes through gloo and host memory "
+                         "(RCCL refuses two ranks on one device); exercises the N>1 control flow, its number means nothing")
     ap.add_argument("--no-two-in-flight", action="store_true", help="N=1: skip the extra two-contexts-in-flight measurement")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="asynchronous steps alternate between this many contexts/streams (default: 2 for N>1, 1 for N=1); "
@@ -118,8 +121,13 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -192,7 +200,15 @@ def main():
     def step_on(sl, want_stats):
         st = sl["it"].render_tile_list_device(scene, cam, sampler, my_list, sl["slab"].data_ptr(), stream=None, want_stats=want_stats)
         if world > 1:
-            dist.gather(sl["slab"], sl["gathered"], dst=0)  # RCCL, ordered after the render through torch's current stream = the slot's
+            if args.rehearse_on_one_gpu:  # gloo gathers host tensors
+                host = sl["slab"].cpu()
+                parts = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, parts, dst=0)
+                if rank == 0:
+                    for r in range(world):
+                        sl["gathered"][r].copy_(parts[r])
+            else:
+                dist.gather(sl["slab"], sl["gathered"], dst=0)  # RCCL, ordered after the render through torch's current stream = the slot's
             if rank == 0:
                 for r in range(world):
                     rank_lists[r].update_film_device(sl["gathered"][r].data_ptr(), wl["res"], sl["film"].data_ptr(), ctx=sl["ctx"])
