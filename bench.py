@@ -16,8 +16,8 @@ per-tile radiance to rank 0, which scatters it into the film (Film::update_tile)
 Total work is fixed -> "scaling": "strong".  Steps are enqueued without host
 synchronisation, alternately on two contexts (frames in flight = 2), so the latency
 tail of one step overlaps the bulk of the next; N = 1 times synchronous steps (live
-per-kernel HIP-event timings) and reports the two-in-flight rate beside them in
-`extra.two_in_flight`.
+per-kernel HIP-event timings); `--two-in-flight` adds the two-in-flight rate of the same
+steps as `extra.two_in_flight`.
 
 Metric = the reference's own: closest-hit rays / second (path.rs:87,
 app/window.rs:911-916); shadow rays are traced but not counted.
@@ -103,7 +103,9 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 rehearsal on a single GPU: every rank uses cuda:0 and the gather goes through gloo and host memory "
                          "(RCCL refuses two ranks on one device); exercises the N>1 control flow, its number means nothing")
-    ap.add_argument("--no-two-in-flight", action="store_true", help="N=1: skip the extra two-contexts-in-flight measurement")
+    ap.add_argument("--two-in-flight", action="store_true",
+                    help="N=1: after the timed region, also time the same K steps asynchronously on two contexts (extra.two_in_flight); "
+                         "off by default so that a rocprofv3 summary of the default command holds undisturbed launches only")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="asynchronous steps alternate between this many contexts/streams (default: 2 for N>1, 1 for N=1); "
                          "the latency tail of step k then overlaps the bulk of step k+1")
@@ -261,7 +263,7 @@ def main():
     # N = 1, synchronous default: also time the same K steps enqueued asynchronously on two
     # contexts — what N > 1 does by default — so that the scaling figures have a like-for-like base.
     two_in_flight = None
-    if world == 1 and in_flight == 1 and not args.no_two_in_flight:
+    if world == 1 and in_flight == 1 and args.two_in_flight:
         c2 = yk.Context(local_rank, **opts)
         pair = [(ctx, it, slab, film), (c2, yk.IntegratorType.instantiate(c2, integ), torch.zeros_like(slab), torch.zeros_like(film))]
 

@@ -15,7 +15,8 @@ mine = ydist.shard_tiles(tiles, 0, G)
 smp = yk.SamplerType.Stratified((8, 8), True)
 dev = torch.device("cuda:0")
 sets = []
-for i in range(2):
+NCTX = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 2
+for i in range(NCTX):
     ctx = yk.Context(0)
     sc = yk.Scene(ctx, sd)
     cam = yk.Camera(sd.camera, fs)
@@ -38,6 +39,6 @@ def run(n_sets):
     return dt / K * 1e3
 
 a = run(1)
-b = a if "one" in sys.argv else run(2)
-print(f"G={G}: one context {a:.2f} ms/render, two alternating contexts {b:.2f} ms/render")
-assert torch.equal(sets[0][5], sets[1][5])
+b = a if "one" in sys.argv else run(NCTX)
+print(f"G={G}: one context {a:.2f} ms/render, {NCTX} alternating contexts {b:.2f} ms/render")
+assert all(torch.equal(sets[0][5], x[5]) for x in sets[1:])
