@@ -199,3 +199,42 @@ def test_prepared_tile_list_matches_the_array_entry_points(ctx, yk):
     got_acc = slab.cpu().numpy().reshape(-1, 3)
     want_acc, _ = it.render_tiles_accumulating(sc, cam, smp, tiles, np.full(len(tiles), 2, dtype=np.uint16))
     assert got_acc.tobytes() == want_acc.tobytes()
+
+
+@pytest.mark.gpu
+def test_context_stream_orders_foreign_work_after_a_render(ctx, yk):
+    """yk_context_stream: with no caller stream everything a context does is ordered on its own
+    stream, which a caller may wrap (torch.cuda.ExternalStream) to queue other device work behind
+    a render — what bench.py does with the RCCL gather.  A second context on the device renders
+    the same scene and tile list and scatters with the list made by the first."""
+    import torch
+
+    sd = scenes.by_name("city-tiny")
+    fs = yk.FilmSettings(res=(96, 64), tile_dim=16)
+    cam = yk.Camera(sd.camera, fs)
+    tiles = yk.film_tiles(fs)
+    smp = yk.SamplerType.Stratified((2, 2), True, 0x73B9642E74AC471C)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=5))
+    sc = yk.Scene(ctx, sd)
+    want, _ = yk.IntegratorType.instantiate(ctx, integ).render_tiles(sc, cam, smp, tiles)
+    want_film = yk.update_tiles(tiles, want, fs.res)
+    tl = yk.TileList(ctx, tiles)
+    ctx2 = yk.Context(0)
+    assert ctx.stream_handle and ctx2.stream_handle and ctx.stream_handle != ctx2.stream_handle
+    outs = []
+    for c in (ctx, ctx2):
+        it = yk.IntegratorType.instantiate(c, integ)
+        slab = torch.zeros(tl.n_pixels * 3, dtype=torch.float32, device="cuda:0")
+        film = torch.zeros(64 * 96 * 3, dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        ext = torch.cuda.ExternalStream(c.stream_handle, device=torch.device("cuda:0"))
+        with torch.cuda.stream(ext):
+            it.render_tile_list_device(sc, cam, smp, tl, slab.data_ptr())  # stream=None: the context's own
+            copy = slab.clone()  # torch work queued on the same stream: sees the finished render
+            tl.update_film_device(slab.data_ptr(), fs.res, film.data_ptr(), ctx=c)
+        outs.append((copy, film))
+    torch.cuda.synchronize()
+    for copy, film in outs:
+        assert copy.cpu().numpy().tobytes() == want.tobytes()
+        assert film.cpu().numpy().tobytes() == want_film.tobytes()
+    ctx2.close()

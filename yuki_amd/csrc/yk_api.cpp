@@ -83,8 +83,7 @@ struct yk_context {
 typedef yk_context::WorkSet WorkSet;
 
 struct yk_scene {
-    yk_context* ctx = nullptr;
-    int device = -1;  // copied: a scene may outlive its context (its buffers belong to the device)
+    int device = -1;  // a scene belongs to the device, not to the context that made it: any context there renders it, and it may outlive them
     HostBvh bvh;
     uint32_t n_triangles = 0, n_spheres = 0, n_lights = 0, n_delta_lights = 0;
     yk_scene_info info;
@@ -98,7 +97,6 @@ struct yk_scene {
 // over and over): host copy + the device pixel table, so that rendering and the film update
 // need no upload and no host synchronisation.
 struct yk_tile_list {
-    yk_context* ctx = nullptr;
     int device = -1;
     std::vector<yk_tile> tiles;
     std::vector<uint16_t> samples;  // empty: plain film
@@ -446,7 +444,6 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
     }
 
     yk_scene* s = new yk_scene();
-    s->ctx = ctx;
     s->device = ctx ? ctx->device : -1;
     s->n_triangles = d->n_triangles;
     s->n_spheres = d->n_spheres;
@@ -1233,7 +1230,6 @@ yk_status yk_tile_list_create(yk_context* ctx, const yk_tile* tiles, const uint1
     if (!tiles || !out || n_tiles == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     yk_tile_list* l = new yk_tile_list();
-    l->ctx = ctx;
     l->device = ctx->device;
     l->tiles.assign(tiles, tiles + n_tiles);
     if (tile_samples) l->samples.assign(tile_samples, tile_samples + n_tiles);
