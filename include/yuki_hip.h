@@ -361,14 +361,17 @@ size_t yk_sizeof(int what);
  *                 implements: perspective Camera, Film resolution, LookAt, Translate/Scale/
  *                 Rotate, Attribute/Transform blocks, Include, (Make)NamedMaterial/Material
  *                 {matte,glass,glossy,metal}, LightSource {infinite,distant,point}, Shape
- *                 {sphere,trianglemesh,plymesh}, Texture "spectrum" "imagemap" (PNG) for matte Kd.
+ *                 {sphere,trianglemesh,plymesh}, Texture "spectrum" "imagemap" for matte Kd.
  * split_method / max_shapes_in_node are SceneLoadSettings (scene/mod.rs:25-39) and are
  * copied into the description.  Errors: where the reference returns LoadError or panics
  * the call returns non-zero and yk_loader_last_error() (thread-local) holds the reason. */
 /* ImageTexture::new(path) (textures/image_texture.rs:66-70,114-141): decode an image file
- * into RGB f32 (u8 / 255, u16 / 65535, no gamma).  PNG only (the `image` crate's other
- * formats return YK_ERR_UNSUPPORTED); gray / gray-alpha files are the reference's
- * "Unsupported image format".  out->rgb is owned by the library: yk_image_texture_free. */
+ * into RGB f32 (u8 / 255, u16 / 65535, float as is, no gamma, alpha dropped).  The decoder
+ * is chosen from the file extension like image::io::Reader::open: .png, .bmp, .tga,
+ * .ppm/.pnm, .qoi, .ff (farbfeld), .exr (scan-line, none/ZIPS/ZIP); the `image` crate's
+ * remaining formats (JPEG, GIF, TIFF, WebP, HDR ...) return YK_ERR_UNSUPPORTED; grey files
+ * are the reference's "Unsupported image format".  out->rgb is owned by the library:
+ * yk_image_texture_free. */
 yk_status yk_image_texture_load(const char* path, yk_texture_desc* out);
 void yk_image_texture_free(yk_texture_desc* tex);
 

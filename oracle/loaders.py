@@ -748,7 +748,7 @@ def _pbrt_file(path, acc, st):
                     if not fn:
                         raise LoadError(f"missing file for texture '{name}'")
                     try:
-                        acc.textures.append(images.load_png(os.path.join(parent, fn)))
+                        acc.textures.append(images.load_image(os.path.join(parent, fn)))
                     except images.ImageError as e:
                         raise LoadError(str(e))
                     st["textures"][name] = len(acc.textures) - 1

@@ -346,3 +346,214 @@ def write_textured_scene(dirname):
     with open(p, "w") as fh:
         fh.write(TEXTURED_PBRT)
     return p
+
+
+# --------------------------------------------------------------------------- other image containers
+# Writers for the formats yk_image_formats.cpp reads, written from the format specifications
+# (independently of both decoders): the source pixel array is the ground truth of the tests.
+def write_bmp(path, img, bits=24, top_down=False, header=40, bitfields=None, palette=None):
+    """img: (h, w, 3) u8 (bits 24/32) or (h, w) palette indices (bits 1/4/8, palette (n, 3) rgb).
+    bitfields = (rmask, gmask, bmask) makes a 32-bit BI_BITFIELDS file."""
+    import struct
+
+    import numpy as np
+
+    h, w = img.shape[:2]
+    stride = (w * bits + 31) // 32 * 4
+    rows = np.zeros((h, stride), dtype=np.uint8)
+    if bits <= 8:
+        b = np.zeros((h, stride * 8), dtype=np.uint8)
+        for k in range(bits):
+            b[:, k : w * bits : bits] = (img >> (bits - 1 - k)) & 1
+        rows[:] = np.packbits(b, axis=1)
+    elif bits == 24:
+        rows[:, : w * 3] = img[:, :, ::-1].reshape(h, w * 3)
+    else:
+        if bitfields:
+            sh = [(m & -m).bit_length() - 1 for m in bitfields]
+            v = sum(img[:, :, k].astype(np.uint32) << sh[k] for k in range(3)) | np.uint32(0x5A << [s for s in (0, 8, 16, 24) if s not in sh][0])
+        else:
+            v = (img[:, :, 0].astype(np.uint32) << 16) | (img[:, :, 1].astype(np.uint32) << 8) | img[:, :, 2].astype(np.uint32) | np.uint32(0x7F000000)
+        rows[:, : w * 4] = v.astype("<u4").view(np.uint8).reshape(h, w * 4)
+    if not top_down:
+        rows = rows[::-1]
+    pal = b""
+    if bits <= 8:
+        esz = 3 if header == 12 else 4
+        pal = b"".join(bytes([p[2], p[1], p[0]]) + (b"\0" if esz == 4 else b"") for p in palette)
+    comp = 3 if bitfields else 0
+    if header == 12:
+        hd = struct.pack("<IHHHH", 12, w, h, 1, bits)
+    else:
+        hd = struct.pack("<IiiHHIIiiII", header, w, -h if top_down else h, 1, bits, comp, stride * h, 2835, 2835, len(palette) if (bits <= 8 and len(palette) != 1 << bits) else 0, 0)
+        extra = header - 40
+        masks = struct.pack("<III", *bitfields) if bitfields else b""
+        if header == 40:
+            hd += masks
+        else:
+            hd += (masks + b"\0" * extra)[:extra] if bitfields else b"\0" * extra
+    off = 14 + len(hd) + len(pal)
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", off + stride * h, 0, 0, off) + hd + pal + rows.tobytes())
+
+
+def write_tga(path, img, alpha=False, rle=False, top_left=False, cmap=None, id_field=b""):
+    """img (h, w, 3) u8 true colour, or (h, w) indices with cmap (n, 3) rgb."""
+    import struct
+
+    import numpy as np
+
+    h, w = img.shape[:2]
+    if cmap is not None:
+        px = img.astype(np.uint8).reshape(h, w, 1)
+        cm = b"".join(bytes([c[2], c[1], c[0]]) for c in cmap)
+        typ, cmt, cm_len, cm_bits, depth = 1, 1, len(cmap), 24, 8
+    else:
+        px = img[:, :, ::-1].astype(np.uint8)
+        if alpha:
+            px = np.concatenate([px, np.full((h, w, 1), 200, dtype=np.uint8)], axis=2)
+        cm, typ, cmt, cm_len, cm_bits, depth = b"", 2, 0, 0, 0, 32 if alpha else 24
+    if not top_left:
+        px = px[::-1]
+    pb = px.shape[2]
+    flat = px.reshape(-1, pb)
+    if rle:
+        typ += 8
+        out, i, n = bytearray(), 0, len(flat)
+        while i < n:
+            run = 1
+            while i + run < n and run < 128 and (flat[i + run] == flat[i]).all():
+                run += 1
+            if run > 1:
+                out += bytes([0x80 | (run - 1)]) + flat[i].tobytes()
+                i += run
+            else:
+                lit = 1
+                while i + lit < n and lit < 128 and not (i + lit + 1 < n and (flat[i + lit] == flat[i + lit + 1]).all()):
+                    lit += 1
+                out += bytes([lit - 1]) + flat[i : i + lit].tobytes()
+                i += lit
+        body = bytes(out)
+    else:
+        body = flat.tobytes()
+    hd = struct.pack("<BBBHHBHHHHBB", len(id_field), cmt, typ, 0, cm_len, cm_bits, 0, 0, w, h, depth, (0x20 if top_left else 0) | (8 if alpha else 0))
+    with open(path, "wb") as f:
+        f.write(hd + id_field + cm + body)
+
+
+def write_ppm(path, img, maxval=255, ascii=False, comment=True):
+    import numpy as np
+
+    h, w = img.shape[:2]
+    head = ("P3" if ascii else "P6") + "\n" + ("# made by the tests\n" if comment else "") + f"{w} {h}\n{maxval}\n"
+    with open(path, "wb") as f:
+        f.write(head.encode())
+        if ascii:
+            f.write((" ".join(str(int(v)) for v in img.reshape(-1)) + "\n").encode())
+        else:
+            f.write(img.astype(">u2" if maxval > 255 else np.uint8).tobytes())
+
+
+def write_qoi(path, img, alpha=None):
+    """Reference-style QOI encoder (all op kinds)."""
+    import struct
+
+    import numpy as np
+
+    h, w = img.shape[:2]
+    ch = 4 if alpha is not None else 3
+    px = np.concatenate([img, alpha[:, :, None]], axis=2) if alpha is not None else np.concatenate([img, np.full((h, w, 1), 255)], axis=2)
+    px = px.reshape(-1, 4).astype(np.int64)
+    out = bytearray(b"qoif" + struct.pack(">IIBB", w, h, ch, 0))
+    seen = [(0, 0, 0, 0)] * 64
+    prev, run = (0, 0, 0, 255), 0
+    for i, p in enumerate(map(tuple, px)):
+        if p == prev:
+            run += 1
+            if run == 62 or i == len(px) - 1:
+                out.append(0xC0 | (run - 1))
+                run = 0
+            continue
+        if run:
+            out.append(0xC0 | (run - 1))
+            run = 0
+        k = (p[0] * 3 + p[1] * 5 + p[2] * 7 + p[3] * 11) % 64
+        if seen[k] == p:
+            out.append(k)
+        else:
+            seen[k] = p
+            if p[3] == prev[3]:
+                d = [((p[c] - prev[c] + 128) & 255) - 128 for c in range(3)]
+                dr_dg, db_dg = d[0] - d[1], d[2] - d[1]
+                if all(-2 <= v <= 1 for v in d):
+                    out.append(0x40 | ((d[0] + 2) << 4) | ((d[1] + 2) << 2) | (d[2] + 2))
+                elif -32 <= d[1] <= 31 and -8 <= dr_dg <= 7 and -8 <= db_dg <= 7:
+                    out += bytes([0x80 | (d[1] + 32), ((dr_dg + 8) << 4) | (db_dg + 8)])
+                else:
+                    out += bytes([0xFE, p[0], p[1], p[2]])
+            else:
+                out += bytes([0xFF, p[0], p[1], p[2], p[3]])
+        prev = p
+    out += b"\0" * 7 + b"\1"
+    with open(path, "wb") as f:
+        f.write(bytes(out))
+
+
+def write_farbfeld(path, img16):
+    import struct
+
+    import numpy as np
+
+    h, w = img16.shape[:2]
+    px = np.concatenate([img16, np.full((h, w, 1), 65535)], axis=2).astype(">u2")
+    with open(path, "wb") as f:
+        f.write(b"farbfeld" + struct.pack(">II", w, h) + px.tobytes())
+
+
+def write_exr(path, img, compression=0, half=False, extra_channels=(), data_origin=(0, 0)):
+    """Scan-line OpenEXR: img (h, w, 3) float32; compression 0 (none), 2 (ZIPS), 3 (ZIP);
+    `extra_channels` adds named FLOAT channels ('A', 'Z', ...) filled with 0.25."""
+    import struct
+    import zlib
+
+    import numpy as np
+
+    h, w = img.shape[:2]
+    chans = sorted([("R", img[:, :, 0]), ("G", img[:, :, 1]), ("B", img[:, :, 2])] + [(n, np.full((h, w), 0.25, dtype=np.float32)) for n in extra_channels])
+    pt = 1 if half else 2
+
+    def attr(name, typ, body):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(body)) + body
+
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<IBxxxII", pt if n in "RGB" else 2, 0, 1, 1) for n, _ in chans) + b"\0"
+    x0, y0 = data_origin
+    box = struct.pack("<iiii", x0, y0, x0 + w - 1, y0 + h - 1)
+    hd = struct.pack("<II", 20000630, 2)
+    hd += attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression]))
+    hd += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0")
+    hd += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0))
+    hd += attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lpc = 16 if compression == 3 else 1
+    chunks = []
+    for r0 in range(0, h, lpc):
+        raw = b""
+        for r in range(r0, min(h, r0 + lpc)):
+            for n, a in chans:
+                raw += a[r].astype("<f2" if (half and n in "RGB") else "<f4").tobytes()
+        body = raw
+        if compression:
+            t = np.frombuffer(raw, dtype=np.uint8)
+            t = np.concatenate([t[0::2], t[1::2]])
+            d = t.astype(np.int64)
+            d[1:] = (d[1:] - t[:-1].astype(np.int64) + 128 + 256) & 255
+            z = zlib.compress(d.astype(np.uint8).tobytes(), 6)
+            body = z if len(z) < len(raw) else raw
+        chunks.append(struct.pack("<iI", y0 + r0, len(body)) + body)
+    table_at = len(hd)
+    off = table_at + 8 * len(chunks)
+    table = b""
+    for c in chunks:
+        table += struct.pack("<Q", off)
+        off += len(c)
+    with open(path, "wb") as f:
+        f.write(hd + table + b"".join(chunks))

@@ -1,4 +1,4 @@
-"""Malformed input never takes the parsers down: mutated PLY / pbrt-v3 / PNG files are either
+"""Malformed input never takes the parsers down: mutated PLY / pbrt-v3 / PNG / BMP / TGA / PPM / QOI / farbfeld / EXR files are either
 loaded or rejected with an error (the reference returns LoadError or panics; a C ABI must not
 crash).  The same corpus is run under AddressSanitizer by tools/asan/run.sh (CPU build)."""
 import os
@@ -12,6 +12,9 @@ from yuki_amd._ffi import YukiError
 import scene_files as sf
 
 
+IMAGE_EXTS = ["bmp", "tga", "ppm", "qoi", "ff", "exr"]
+
+
 def _seeds(d):
     sf.write_ascii_ply(os.path.join(d, "a.ply"))
     sf.write_binary_ply(os.path.join(d, "b.ply"))
@@ -22,12 +25,27 @@ def _seeds(d):
     sf.write_png(os.path.join(d, "r.png"), (np.arange(35).reshape(5, 7) % 4).astype(np.uint8), depth=2, palette=pal)
     pb = sf.write_scene(d)
     tx = sf.write_textured_scene(d)
+    img = sf.test_pattern(9, 7).astype(np.uint8)
+    sf.write_bmp(os.path.join(d, "s.bmp"), img)
+    sf.write_bmp(os.path.join(d, "t.bmp"), (np.arange(35).reshape(5, 7) % 4).astype(np.uint8), bits=4, palette=pal)
+    sf.write_bmp(os.path.join(d, "u.bmp"), img, bits=32, bitfields=(0xFF, 0xFF00, 0xFF0000), header=108)
+    sf.write_tga(os.path.join(d, "s.tga"), img, rle=True, alpha=True)
+    sf.write_tga(os.path.join(d, "t.tga"), (np.arange(35).reshape(5, 7) % 4).astype(np.uint8), cmap=pal, rle=True)
+    sf.write_ppm(os.path.join(d, "s.ppm"), img)
+    sf.write_ppm(os.path.join(d, "t.ppm"), img, ascii=True)
+    sf.write_qoi(os.path.join(d, "s.qoi"), img)
+    sf.write_farbfeld(os.path.join(d, "s.ff"), img.astype(np.int64) * 257)
+    sf.write_exr(os.path.join(d, "s.exr"), img.astype(np.float32), compression=3, half=True, extra_channels=("A",))
+    sf.write_exr(os.path.join(d, "t.exr"), img.astype(np.float32))
     rd = lambda p: open(p, "rb").read()
-    return {
+    out = {
         "ply": [rd(os.path.join(d, n)) for n in ("a.ply", "b.ply", "c.ply")],
         "png": [rd(os.path.join(d, n)) for n in ("p.png", "q.png", "r.png")],
         "pbrt": [rd(pb), rd(tx)],
     }
+    for ext, names in (("bmp", "stu"), ("tga", "st"), ("ppm", "st"), ("qoi", "s"), ("ff", "s"), ("exr", "st")):
+        out[ext] = [rd(os.path.join(d, f"{n}.{ext}")) for n in names]
+    return out
 
 
 def _mutate(rng, b):
@@ -55,7 +73,7 @@ def write_corpus(d, seed=1, count=1000):
     seeds = _seeds(d)
     paths = []
     for i in range(count):
-        kind = rng.choice(["ply", "png", "pbrt"])
+        kind = rng.choice(["ply", "png", "pbrt", "ply", "png", "pbrt"] + IMAGE_EXTS)
         p = os.path.join(d, f"fz{i:05d}.{kind}")
         with open(p, "wb") as f:
             f.write(_mutate(rng, rng.choice(seeds[kind])))
@@ -65,11 +83,11 @@ def write_corpus(d, seed=1, count=1000):
 
 def test_mutated_files_are_loaded_or_rejected(tmp_path):
     loaded = rejected = 0
-    for p in write_corpus(str(tmp_path), seed=3, count=600):
+    for p in write_corpus(str(tmp_path), seed=3, count=900):
         try:
             if p.endswith(".ply"):
                 loaders.load_ply(p)
-            elif p.endswith(".png"):
+            elif p.rsplit(".", 1)[-1] in ["png"] + IMAGE_EXTS:
                 loaders.load_image_texture(p)
             else:
                 loaders.load_pbrt(p)

@@ -8,7 +8,7 @@ ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=${TMPDIR:-/tmp}/yk_asan
 mkdir -p $OUT/corpus
 cd $ROOT/yuki_amd/csrc
-hipcc -x hip --cuda-host-only -O1 -g -fsanitize=address -shared-libasan -std=c++17 -fPIC -ffp-contract=off -shared -o $OUT/libyk_host_asan.so yk_loaders.cpp yk_image.cpp yk_host.cpp 2>/dev/null
+hipcc -x hip --cuda-host-only -O1 -g -fsanitize=address -shared-libasan -std=c++17 -fPIC -ffp-contract=off -shared -o $OUT/libyk_host_asan.so yk_loaders.cpp yk_image.cpp yk_image_formats.cpp yk_host.cpp 2>/dev/null
 /opt/rocm/lib/llvm/bin/clang++ -O1 -g -fsanitize=address -shared-libasan -std=c++17 $ROOT/tools/asan/harness.cpp -o $OUT/harness -L$OUT -lyk_host_asan -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$OUT
 rm -f $OUT/corpus/fz*
 cd $ROOT && python -c "

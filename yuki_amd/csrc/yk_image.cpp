@@ -8,7 +8,8 @@
 //   * gray, gray+alpha            -> Luma*/LumaA* -> the reference's "Unsupported image format"
 //   * no gamma / sRGB conversion, alpha dropped, Adam7 interlace supported, CRC and
 //     Adler-32 verified (a corrupt file is a decode error in the reference too).
-// Other container formats of the `image` crate (JPEG, BMP, EXR, ...) are not implemented.
+// The decoder is chosen from the file extension, like image::io::Reader::open; the other
+// containers (BMP, TGA, PPM, QOI, farbfeld, EXR) live in yk_image_formats.cpp.
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -18,6 +19,7 @@
 
 #include "../../include/yuki_hip.h"
 #include "yk_host.h"
+#include "yk_image_internal.h"
 
 namespace {
 
@@ -234,7 +236,7 @@ bool unfilter(uint8_t* data, size_t rows, size_t stride, size_t bpp) {
 
 yk_status decode_png(const std::vector<uint8_t>& f, uint32_t& W, uint32_t& H, std::vector<float>& rgb) {
     static const uint8_t SIG[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-    if (f.size() < 8 || std::memcmp(f.data(), SIG, 8) != 0) return ifail(YK_ERR_UNSUPPORTED, "not a PNG file (other image formats are not implemented)");
+    if (f.size() < 8 || std::memcmp(f.data(), SIG, 8) != 0) return ifail(YK_ERR_UNSUPPORTED, "PNG: bad signature");
     size_t pos = 8;
     uint32_t depth = 0, ctype = 0, interlace = 0;
     bool have_hdr = false, have_trns = false, ended = false;
@@ -321,6 +323,13 @@ yk_status decode_png(const std::vector<uint8_t>& f, uint32_t& W, uint32_t& H, st
 
 }  // namespace
 
+bool yk_img::yk_inflate_zlib(const uint8_t* src, size_t n, std::vector<uint8_t>& out) {
+    out.clear();
+    if (n < 6 || (src[0] & 0x0f) != 8 || ((src[0] << 8) | src[1]) % 31 != 0 || (src[1] & 0x20)) return false;
+    if (!inflate(src + 2, n - 6, out)) return false;
+    return adler32(out) == be32(src + n - 4);
+}
+
 // used by the pbrt loader (yk_loaders.cpp)
 yk_status yk_image_decode_file(const std::string& path, uint32_t& w, uint32_t& h, std::vector<float>& rgb, std::string& err) {
     std::vector<uint8_t> bytes;
@@ -329,6 +338,12 @@ yk_status yk_image_decode_file(const std::string& path, uint32_t& w, uint32_t& h
         return YK_ERR_INVALID_ARGUMENT;
     }
     yk_status st;
+    bool is_png = false;
+    st = yk_img::decode_by_extension(path, bytes, w, h, rgb, err, is_png);
+    if (!is_png) {
+        if (st != YK_OK) err += " (" + path + ")";
+        return st;
+    }
     try {
         st = decode_png(bytes, w, h, rgb);
     } catch (const std::exception& e) {
