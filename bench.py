@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--async-steps", action="store_true", help="N=1: enqueue the timed steps without host synchronisation, as N>1 always does")
     ap.add_argument("--cpu-sample-tiles", type=int, default=384)
+    ap.add_argument("--rccl-single", action="store_true",
+                    help="N=1 through the N>1 code path: a one-rank RCCL process group, asynchronous slots, gather, scatter "
+                         "(checks the collective's ordering on the context streams on a single GPU)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 rehearsal on a single GPU: every rank uses cuda:0 and the gather goes through gloo and host memory "
                          "(RCCL refuses two ranks on one device); exercises the N>1 control flow, its number means nothing")
@@ -119,8 +122,15 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.rccl_single  # the multi-rank control flow (also with one rank, for rehearsal)
+    if use_dist:
         import torch.distributed as dist
+
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.rehearse_on_one_gpu:
@@ -164,20 +174,20 @@ def main():
     slab_px = ydist.slab_pixels(tiles, world)
     slab = torch.zeros(slab_px * 3, dtype=torch.float32, device=dev)
     film = torch.zeros(wl["res"][1] * wl["res"][0] * 3, dtype=torch.float32, device=dev) if rank == 0 else None
-    gathered = [torch.zeros_like(slab) for _ in range(world)] if (rank == 0 and world > 1) else None
+    gathered = [torch.zeros_like(slab) for _ in range(world)] if (rank == 0 and use_dist) else None
 
     # Prepared tile lists: the pixel tables live on the device, so a step needs no upload.
     my_list = yk.TileList(ctx, my_tiles)
-    rank_lists = [yk.TileList(ctx, ydist.shard_tiles(tiles, r, world)) for r in range(world)] if (rank == 0 and world > 1) else None
+    rank_lists = [yk.TileList(ctx, ydist.shard_tiles(tiles, r, world)) for r in range(world)] if (rank == 0 and use_dist) else None
     # N > 1 (or --async-steps): every launch of a step — render, RCCL gather, film scatter — is
     # enqueued on one stream and nothing waits on the host inside the timed region;
     # ray counts are taken from one synchronous step beforehand (every step renders the same frame).
-    async_steps = world > 1 or args.async_steps
+    async_steps = use_dist or args.async_steps
     # Asynchronous steps alternate between `in_flight` slots — a context (work buffers, HIP
     # streams), a torch stream, a slab and gather buffers each — so that the latency tail of step k
     # (late bounces: few rays, every launch as long as its longest ray) runs beside the bulk of
     # step k+1.  Every slot renders the same scene copy and tile list; steps stay ordered per slot.
-    in_flight = max(1, args.frames_in_flight or (2 if world > 1 else 1)) if async_steps else 1
+    in_flight = max(1, args.frames_in_flight or (2 if use_dist else 1)) if async_steps else 1
     slots = [dict(ctx=ctx, it=it, slab=slab, gathered=gathered, film=film)]
     for _ in range(1, in_flight):
         c2 = yk.Context(local_rank, **opts)
@@ -201,7 +211,7 @@ def main():
 
     def step_on(sl, want_stats):
         st = sl["it"].render_tile_list_device(scene, cam, sampler, my_list, sl["slab"].data_ptr(), stream=None, want_stats=want_stats)
-        if world > 1:
+        if use_dist:
             if args.rehearse_on_one_gpu:  # gloo gathers host tensors
                 host = sl["slab"].cpu()
                 parts = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
@@ -220,7 +230,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -250,7 +260,7 @@ def main():
         shadow_launches += st.shadow_launches
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -350,7 +360,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl["desc"], "triangles": sd.n_triangles, "spp": spp, "max_depth": wl["depth"], "tiles": int(len(tiles)),
-                       "partition": f"spiral tiles dealt round-robin to {world} rank(s), RCCL gather to rank 0" if world > 1 else "single GPU",
+                       "partition": f"spiral tiles dealt round-robin to {world} rank(s), RCCL gather to rank 0" if use_dist else "single GPU",
                        "frames_in_flight": in_flight},
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -365,7 +375,7 @@ def main():
     scene.close()
     for sl in slots:
         sl["ctx"].close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
