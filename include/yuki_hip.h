@@ -40,7 +40,7 @@ typedef enum yk_status {
     YK_ERR_NO_DEVICE = 2,        /* HIP runtime / device unavailable */
     YK_ERR_DEVICE = 3,           /* a HIP call failed; see yk_last_error */
     YK_ERR_OUT_OF_MEMORY = 4,
-    YK_ERR_UNSUPPORTED = 5,      /* e.g. Whitted on the device path, unsupported file content */
+    YK_ERR_UNSUPPORTED = 5,      /* e.g. Whitted deeper than 16, yk_li with a debug integrator, unsupported file content */
     YK_ERR_BVH_BUILD = 6,        /* reference: assert_ne!(mid,start) bvh.rs:368 */
     YK_ERR_CANCELLED = 7,        /* early_termination_predicate returned true */
     YK_ERR_STACK_OVERFLOW = 8    /* traversal stack > 64, reference: assert bvh.rs:174 */
@@ -152,7 +152,7 @@ typedef struct yk_sampler_desc {
 
 /* integrators/mod.rs:33-40 `IntegratorType` */
 typedef enum yk_integrator_kind {
-    YK_INTEGRATOR_WHITTED = 0, /* not implemented on the device */
+    YK_INTEGRATOR_WHITTED = 0, /* whitted.rs:39-181; max_depth <= 16 on the device */
     YK_INTEGRATOR_PATH = 1,
     YK_INTEGRATOR_BVH_INTERSECTIONS = 2,
     YK_INTEGRATOR_GEOMETRY_NORMALS = 3,

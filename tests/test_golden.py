@@ -39,7 +39,7 @@ def test_oracle_reproduces_golden_traversal(oracle):
     assert np.array_equal(occ, g["occluded"])
 
 
-GPU_CASES = [n for n, c in mg.CASES.items() if c[3].kind != abi.INTEGRATOR_WHITTED]  # Whitted: oracle only
+GPU_CASES = list(mg.CASES)  # incl. cfg1's Whitted (one lane per camera sample, k_whitted)
 
 
 @pytest.mark.gpu

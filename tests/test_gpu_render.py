@@ -61,6 +61,31 @@ def test_path_render_matches_oracle(ctx, yk, oracle, name, res, skind, depth):
     assert mism == 0, f"{mism} of {got.size} channel values differ from the oracle bit pattern"
 
 
+WHITTED_CASES = [
+    ("cornell", (96, 96), "uniform", 3),  # BASELINE configs[0]: built-in Cornell, Whitted max_depth 3 (the copper sphere: no specular lobes)
+    ("cornell", (64, 64), "stratified", 1),
+    ("glass-balls", (96, 64), "uniform", 5),  # nested reflection + transmission subtrees, total internal reflection, area light seen through glass
+    ("glass-balls", (96, 64), "stratified", 3),
+    ("glass-balls", (64, 48), "uniform", 16),
+    ("city-tiny", (128, 72), "stratified", 4),
+    ("city-small", (96, 54), "uniform", 3),
+]
+
+
+@pytest.mark.parametrize("name,res,skind,depth", WHITTED_CASES)
+def test_whitted_render_matches_oracle(ctx, yk, oracle, name, res, skind, depth):
+    """Whitted::li_internal (whitted.rs:74-181): recursion order, shared sampler, (f * li) * |cos| without pdf."""
+    sd = scenes.by_name(name)
+    sampler = yk.SamplerType.Uniform(4, SEED) if skind == "uniform" else yk.SamplerType.Stratified((2, 2), True, SEED)
+    integ = yk.IntegratorType.Whitted(depth)
+    got, stats, want, rays = _render_both(ctx, yk, oracle, sd, res, sampler, integ)
+    assert stats.rays == rays  # li_internal calls
+    assert np.isfinite(want).all() and want.max() > 0
+    assert _rmse(got, want) < TOL_RMSE
+    mism = int((_bits(got) != _bits(want)).sum())
+    assert mism == 0, f"{mism} of {got.size} channel values differ from the oracle bit pattern"
+
+
 def test_indirect_clamp(ctx, yk, oracle):
     sd = scenes.by_name("city-tiny")
     sampler = yk.SamplerType.Uniform(4, SEED)
@@ -155,8 +180,11 @@ def test_li_matches_render(ctx, yk, oracle):
     fs = yk.FilmSettings(res=(32, 32), tile_dim=32)
     cam = yk.Camera(sd.camera, fs)
     sc = yk.Scene(ctx, sd)
-    for sampler in (yk.SamplerType.Uniform(1, SEED), yk.SamplerType.Stratified((1, 1), True, SEED)):
-        it = yk.IntegratorType.instantiate(ctx, yk.IntegratorType.Path(yk.PathParams(max_depth=6)))
+    import itertools
+
+    for sampler, integ in itertools.product((yk.SamplerType.Uniform(1, SEED), yk.SamplerType.Stratified((1, 1), True, SEED)),
+                                            (yk.IntegratorType.Path(yk.PathParams(max_depth=6)), yk.IntegratorType.Whitted(4))):
+        it = yk.IntegratorType.instantiate(ctx, integ)
         tile = (0, 0, 32, 32)
         px, _ = it.render(sc, cam, sampler, yk.FilmTile(bb=tile))
         o, d = yk.camera_rays(ctx, cam, sampler, tile, 0)
@@ -174,8 +202,8 @@ def test_error_behaviour(ctx, yk):
     with pytest.raises(yk.YukiError) as e:
         it.render(sc, cam, yk.SamplerType.Uniform(1), yk.FilmTile(bb=(8, 8, 8, 16)))  # Bounds2 with a dimension <= 0
     assert e.value.status == 1
-    with pytest.raises(yk.YukiError) as e:
-        yk.IntegratorType.instantiate(ctx, yk.IntegratorType.Whitted(3)).render(sc, cam, yk.SamplerType.Uniform(1), yk.FilmTile(bb=(0, 0, 8, 8)))
+    with pytest.raises(yk.YukiError) as e:  # the device kernel keeps at most 16 suspended calls
+        yk.IntegratorType.instantiate(ctx, yk.IntegratorType.Whitted(17)).render(sc, cam, yk.SamplerType.Uniform(1), yk.FilmTile(bb=(0, 0, 8, 8)))
     assert e.value.status == 5
     # cancellation: the predicate is polled before every batch
     with pytest.raises(yk.YukiError) as e:

@@ -856,7 +856,8 @@ static yk_status make_params(yk_context* ctx, const yk_sampler_desc* smp, const 
     prm.has_clamp = integ->has_clamp;
     prm.clamp = integ->indirect_clamp;
     prm.integrator = integ->kind;
-    if (integ->kind == YK_INTEGRATOR_WHITTED) return fail(ctx, YK_ERR_UNSUPPORTED, "Whitted has no device kernel (CPU oracle only)");
+    if (integ->kind == YK_INTEGRATOR_WHITTED && integ->max_depth > whitted_max_depth())
+        return fail(ctx, YK_ERR_UNSUPPORTED, "Whitted: max_depth above 16 is not supported on the device");
     if (integ->kind > YK_INTEGRATOR_SHADING_NORMALS) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "bad integrator kind");
     return YK_OK;
 }
@@ -1143,6 +1144,13 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
             if (is_path) {
                 run_bounces(ctx, ws, bs, scene, prm, pixel_xy, pixel_sample, sample_buf, kt, counters, true, &n_shadow);
                 n_trace += prm.max_depth;
+            } else if (prm.integrator == YK_INTEGRATOR_WHITTED) {
+                // one lane per camera sample runs the whole recursion (whitted.rs:74-181)
+                int e = kt.begin(bs);
+                launch_whitted(bs, trace_grid(ctx), scene->dev, prm, pixel_xy, pixel_sample, path_buffers(ws, 0), n, sample_buf, ws.spill.as<uint2>(),
+                               trace_grid(ctx) * trace_block_size(), ctrl, counters);
+                kt.end(e, 0, bs);
+                ++n_trace;
             } else {
                 PathBuffers pc = path_buffers(ws, 0);
                 const bool want_stats = prm.integrator == YK_INTEGRATOR_BVH_INTERSECTIONS;
@@ -1415,7 +1423,8 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
     RenderParams prm;
     yk_status ps = make_params(ctx, sampler, integrator, prm);
     if (ps != YK_OK) return ps;
-    if (prm.integrator != YK_INTEGRATOR_PATH) return fail(ctx, YK_ERR_UNSUPPORTED, "yk_li implements the Path integrator");
+    if (prm.integrator != YK_INTEGRATOR_PATH && prm.integrator != YK_INTEGRATOR_WHITTED)
+        return fail(ctx, YK_ERR_UNSUPPORTED, "yk_li implements the Path and Whitted integrators");
     if (prm.max_depth > YK_CTRL_MAX_DEPTH) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "max_depth too large");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
@@ -1441,7 +1450,11 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
     KernelTimer kt;
     kt.ctx = ctx;
     kt.on = false;
-    run_bounces(ctx, ctx->ws[0], st, scene, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), ctx->sample_buf.as<float4>(), kt, counters, false);
+    if (prm.integrator == YK_INTEGRATOR_WHITTED)
+        launch_whitted(st, trace_grid(ctx), scene->dev, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), path_buffers(ctx->ws[0], 0), (uint32_t)n,
+                       ctx->sample_buf.as<float4>(), ctx->ws[0].spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), ctrl, counters);
+    else
+        run_bounces(ctx, ctx->ws[0], st, scene, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), ctx->sample_buf.as<float4>(), kt, counters, false);
     HIP_TRY(ctx, hipGetLastError());
     std::vector<float> tmp(n * 4);
     HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->sample_buf.p, n * 16, hipMemcpyDeviceToHost, st));

@@ -323,4 +323,31 @@ YK_HD BsdfSample bsdf_sample_f(const Material& m, const Frame& fr, V3 wo_world, 
     return s;
 }
 
+// Bsdf::sample_f(wo, Point2(0, 0), SPECULAR | REFLECTION or SPECULAR | TRANSMISSION) — what
+// Whitted::specular_contribution asks for (whitted.rs:49-51).  Only lobes whose type is
+// inside the mask match (bsdfs/mod.rs:150-160): glass is the only material with specular
+// lobes and exactly one of its two matches, so matching_comps = 1, the lobe's pdf of 1 is not
+// divided, and u is irrelevant.  BX_NONE = no matching lobe, or total internal reflection.
+YK_HD BsdfSample bsdf_sample_specular(const Material& m, const Frame& fr, V3 wo_world, int direction) {
+    if (m.kind != MK_GLASS) return bsdf_sample_none();
+    V3 wo = world_to_local(fr, wo_world);
+    BsdfSample s;
+    V3 wi;
+    if (direction == BX_REFLECTION) {  // specular.rs:24-34
+        wi = V3{-wo.x, -wo.y, wo.z};
+        s.f = RGB{m.a[0], m.a[1], m.a[2]} * fresnel_dielectric(1.0f, m.c, cos_theta(wi)) / fabsf(cos_theta(wi));
+        s.type = BX_SPECULAR | BX_REFLECTION;
+    } else {  // specular.rs:68-92
+        bool entering = cos_theta(wo) > 0.0f;
+        float eta_i = entering ? 1.0f : m.c;
+        float eta_t = entering ? m.c : 1.0f;
+        if (!refract(wo, faceforward_v(V3{0.0f, 0.0f, 1.0f}, wo), eta_i / eta_t, wi)) return bsdf_sample_none();
+        s.f = RGB{m.b[0], m.b[1], m.b[2]} * (RGB{1.0f, 1.0f, 1.0f} - fresnel_dielectric(1.0f, m.c, cos_theta(wi))) / fabsf(cos_theta(wi));
+        s.type = BX_SPECULAR | BX_TRANSMISSION;
+    }
+    s.wi = local_to_world(fr, wi);
+    s.pdf = 1.0f;
+    return s;
+}
+
 }  // namespace yk

@@ -26,6 +26,9 @@ void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, 
 void launch_trace_closest(hipStream_t s, unsigned grid, const DevScene& sc, const float4* rayO, const float4* rayD, const float* t_max_opt,
                           const unsigned* count_ptr, unsigned* head, int* hit_tri, float4* hit_out, uint4* stats_out, uint2* spill,
                           unsigned spill_stride, unsigned* ctrl, unsigned long long* ray_counter);
+void launch_whitted(hipStream_t s, unsigned grid, const DevScene& sc, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
+                    PathBuffers cur, uint32_t n, float4* sample_buf, uint2* spill, unsigned spill_stride, unsigned* ctrl, unsigned long long* counters);
+unsigned whitted_max_depth();
 void launch_trace_any(hipStream_t s, unsigned grid, const DevScene& sc, const float4* shO, const float4* shD, const unsigned* slot_of,
                       const unsigned* count_ptr, unsigned* head, unsigned char* vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
                       unsigned long long* shadow_counter);

@@ -721,6 +721,220 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(DevScene sc, const floa
 }
 
 
+// ------------------------------------------------------------------ Whitted
+// BoundingVolumeHierarchy::any_intersect (bvh.rs:235-302) for one lane: true = occluded.  A hit
+// on the sampled area light's own surface does not occlude (bvh.rs:269-280).
+template <int BLOCK, int LDS_DEPTH>
+__device__ __forceinline__ bool traverse_any(const DevScene& sc, V3 o, V3 d, float t_max, int area_light, TravStack<BLOCK, LDS_DEPTH>& stk, unsigned* err) {
+    V3 inv = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    bool neg[3] = {inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f};
+    RayTri rt = ray_tri_setup(d);
+    float tmin;
+    if (!slab(V3{sc.root_bmin[0], sc.root_bmin[1], sc.root_bmin[2]}, V3{sc.root_bmax[0], sc.root_bmax[1], sc.root_bmax[2]}, o, inv, t_max, tmin)) return false;
+    int sp = 0;
+    unsigned cur = sc.root_ref;
+    for (;;) {
+        if (!(cur & YK_LEAF_BIT)) {
+            NodeBoxes nb = load_node(sc.nodes, cur);
+            float t0, t1;
+            bool h0 = slab(nb.lo0, nb.hi0, o, inv, t_max, t0);
+            bool h1 = slab(nb.lo1, nb.hi1, o, inv, t_max, t1);
+            bool swap = neg[nb.axis];
+            unsigned near_ref = swap ? nb.ref1 : nb.ref0, far_ref = swap ? nb.ref0 : nb.ref1;
+            bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
+            if (near_hit) {
+                if (far_hit) {
+                    if (sp >= YK_REF_STACK_CAP) {
+                        atomicOr(err, 1u);
+                        return false;
+                    }
+                    stk.push(sp, far_ref, 0.0f);
+                    ++sp;
+                }
+                cur = near_ref;
+                continue;
+            }
+            if (far_hit) {
+                cur = far_ref;
+                continue;
+            }
+        } else {
+            unsigned prim = cur & ~YK_LEAF_BIT;
+            for (;;) {
+                float4 v0 = sc.tris[3 * prim], v1 = sc.tris[3 * prim + 1], v2 = sc.tris[3 * prim + 2];
+                const unsigned pflags = __float_as_uint(v2.w);
+                TriHit h = TriHit{0.0f, 0.0f, 0.0f, 0.0f};
+                bool got;
+                if (pflags & YK_PRIM_SPHERE) {
+                    V3 ro, rd;
+                    got = sphere_hit_t(sc.spheres[__float_as_uint(v1.w) - sc.n_triangles], o, d, t_max, h.t, ro, rd);
+                } else {
+                    got = tri_intersect(o, rt, t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h);
+                }
+                if (got) {
+                    int prim_light = (int)__float_as_uint(v0.w);
+                    if (!(area_light >= 0 && prim_light >= 0 && prim_light == area_light)) return true;
+                }
+                if (pflags & YK_PRIM_LAST) break;
+                ++prim;
+            }
+        }
+        if (sp == 0) return false;
+        --sp;
+        cur = stk.at(sp).x;
+    }
+}
+
+// Whitted::li_internal (whitted.rs:74-181), one lane per camera sample.  The recursion —
+// direct lighting, then the specular reflection subtree, then the specular transmission
+// subtree, each child weighted as (f * li) * |wi . ns| with no pdf (whitted.rs:66) — is run
+// depth first with an explicit frame stack, because the ONE sampler of the pixel sample is
+// drawn from in exactly that order (2 dimensions per light at every hit).  Child rays come from
+// sample_f with u = (0, 0) (whitted.rs:49-51): the tree itself does not depend on the sampler,
+// and only glass has specular lobes, so only glass hits push a frame.
+#define YK_WHITTED_MAX_DEPTH 16
+struct WhittedFrame {
+    RGB sum;          // sum_li of the suspended call
+    RGB pend_f;       // weight of the child being evaluated
+    float pend_cos;
+    bool t_valid;     // the transmission child, evaluated after the reflection subtree
+    V3 t_o, t_d;
+    RGB t_f;
+    float t_cos;
+};
+
+template <int BLOCK, int LDS_DEPTH>
+__global__ __launch_bounds__(BLOCK) void k_whitted(DevScene sc, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab, PathBuffers cur,
+                                                   uint32_t n, float4* sample_buf, uint2* spill, unsigned spill_stride, unsigned* ctrl,
+                                                   unsigned long long* counters) {
+    __shared__ unsigned long long lds_stack[LDS_DEPTH * BLOCK];
+    TravStack<BLOCK, LDS_DEPTH> stk;
+    stk.lds = (lds_u64*)lds_stack;
+    stk.spill = (glb_u64*)spill;
+    stk.spill_stride = spill_stride;
+    stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned* err = ctrl + YK_CTRL_ERR;
+    unsigned long long n_rays = 0, n_shadow = 0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const float4 a = cur.rayO[i], b = cur.rayD[i], c = cur.thru[i];
+        const uint4 r = cur.rngs[i];
+        V3 o = f4_xyz(a), d = f4_xyz(b);
+        const unsigned sid = __float_as_uint(b.w);
+        SamplerState st;
+        st.rng.state = (u64)r.x | ((u64)r.y << 32);
+        st.rng.inc = (u64)r.z | ((u64)r.w << 32);
+        st.dimension = __float_as_uint(c.w);
+        const uint32_t xy = pixel_xy[sample_index_tab ? sid : sid / prm.sampler.spp];
+        st.px = xy & 0xffffu;
+        st.py = xy >> 16;
+        st.sample_index = sample_index_tab ? sample_index_tab[sid] : sid % prm.sampler.spp;
+        WhittedFrame frames[YK_WHITTED_MAX_DEPTH];
+        int sp = 0;  // frames on the stack = depth of the call being evaluated
+        bool is_specular = false;
+        RGB ret = RGB{0.0f, 0.0f, 0.0f};
+        for (;;) {
+            // ---- call: li_internal(ray (o, d), depth = sp, is_specular)
+            n_rays += 1;
+            int shape;
+            TriHit th = TriHit{0.0f, 0.0f, 0.0f, 0.0f};
+            unsigned nt = 0, nh = 0, ns = 0;
+            traverse_closest<BLOCK, LDS_DEPTH, false>(sc, o, d, __builtin_inff(), stk, shape, th, nt, nh, ns, err);
+            bool called = false;
+            if (shape < 0) {
+                ret = RGB{sc.background[0], sc.background[1], sc.background[2]};  // whitted.rs:171
+            } else {
+                Surface sf = hit_surface(sc, (uint32_t)shape, o, d);
+                Material mat = sc.materials[sf.material];
+                if (mat.tex) {  // matte.rs:29-30
+                    RGB kd = texture_eval(sc, mat.tex - 1u, sf.u, sf.v);
+                    mat.a[0] = kd.r;
+                    mat.a[1] = kd.g;
+                    mat.a[2] = kd.b;
+                    if (is_black(kd)) mat.kind = MK_BLACK;
+                }
+                const Frame fr = make_frame(sf.n, sf.ns, sf.dpdus);
+                RGB sum = RGB{0.0f, 0.0f, 0.0f};
+                for (unsigned l = 0; l < sc.n_lights; ++l) {  // whitted.rs:113-133, the fold of path.rs:102-119
+                    float ux, uy;
+                    sampler_get_2d(prm.sampler, st, ux, uy);
+                    LightSample ls = sample_light(sc.lights[l], (int)l, sf.p, ux, uy);
+                    if (is_black(ls.li)) continue;
+                    RGB f = bsdf_f(mat, fr, sf.wo, ls.l);
+                    if (!ls.has_vis || is_black(f)) continue;
+                    V3 offset = sf.n * 0.001f;  // VisibilityTester::ray = p0.spawn_ray_to(p1), interaction.rs:44-59
+                    V3 so = dot(ls.p1 - sf.p, sf.n) > 0.0f ? sf.p + offset : sf.p - offset;
+                    n_shadow += 1;
+                    if (!traverse_any<BLOCK, LDS_DEPTH>(sc, so, ls.p1 - so, 0.9999f, ls.area_light, stk, err))
+                        sum = sum + f * ls.li * rclamp(dot_nv(sf.ns, ls.l), 0.0f, 1.0f) / ls.pdf;
+                }
+                if (sp == 0 || is_specular) {  // whitted.rs:135-137, rectangular_light.rs:75-81
+                    if (sf.area_light >= 0) {
+                        const DevLight& L = sc.lights[sf.area_light];
+                        sum = sum + (dot_nv(sf.n, -d) > 0.0f ? RGB{L.i[0], L.i[1], L.i[2]} : RGB{0.0f, 0.0f, 0.0f});
+                    } else {
+                        sum = sum + RGB{0.0f, 0.0f, 0.0f};
+                    }
+                }
+                ret = sum;
+                if ((unsigned)sp + 1u < prm.max_depth && mat.kind == MK_GLASS) {  // whitted.rs:139-167
+                    BsdfSample rs = bsdf_sample_specular(mat, fr, sf.wo, BX_REFLECTION);
+                    BsdfSample ts = bsdf_sample_specular(mat, fr, sf.wo, BX_TRANSMISSION);
+                    if (rs.type != BX_NONE || ts.type != BX_NONE) {
+                        WhittedFrame& fm = frames[sp];
+                        fm.sum = sum;
+                        fm.t_valid = false;
+                        const BsdfSample& first = rs.type != BX_NONE ? rs : ts;
+                        if (rs.type != BX_NONE && ts.type != BX_NONE) {
+                            fm.t_valid = true;
+                            fm.t_o = spawn_origin(sf.p, sf.n, ts.wi);
+                            fm.t_d = ts.wi;
+                            fm.t_f = ts.f;
+                            fm.t_cos = fabsf(dot_nv(ts.wi, sf.ns));
+                        }
+                        fm.pend_f = first.f;
+                        fm.pend_cos = fabsf(dot_nv(first.wi, sf.ns));
+                        o = spawn_origin(sf.p, sf.n, first.wi);
+                        d = first.wi;
+                        is_specular = true;  // sample_type.contains(SPECULAR), whitted.rs:64
+                        ++sp;
+                        called = true;
+                    }
+                }
+            }
+            if (called) continue;
+            // ---- return: fold `ret` into the suspended callers
+            bool again = false;
+            while (sp > 0) {
+                WhittedFrame& fm = frames[sp - 1];
+                fm.sum = fm.sum + fm.pend_f * ret * fm.pend_cos;  // ret.li = f * ret.li * |wi . ns| ; sum_li += li
+                if (fm.t_valid) {
+                    fm.t_valid = false;
+                    fm.pend_f = fm.t_f;
+                    fm.pend_cos = fm.t_cos;
+                    o = fm.t_o;
+                    d = fm.t_d;
+                    is_specular = true;
+                    again = true;
+                    break;
+                }
+                ret = fm.sum;
+                --sp;
+            }
+            if (!again) break;
+        }
+        sample_buf[sid] = make_float4(ret.r, ret.g, ret.b, 0.0f);
+    }
+    // ray counts: one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        n_rays += __shfl_down(n_rays, off);
+        n_shadow += __shfl_down(n_shadow, off);
+    }
+    if (lane_id() == 0 && counters) {
+        if (n_rays) atomicAdd(counters, n_rays);
+        if (n_shadow) atomicAdd(counters + 1, n_shadow);
+    }
+}
+
 // ------------------------------------------------------------------ launchers
 #ifndef TRACE_PF_MIN
 #define TRACE_PF_MIN 16
@@ -766,6 +980,12 @@ void launch_trace_closest(hipStream_t s, unsigned grid, const DevScene& sc, cons
 #undef YK_LAUNCH_CLOSEST
     }
 }
+void launch_whitted(hipStream_t s, unsigned grid, const DevScene& sc, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
+                    PathBuffers cur, uint32_t n, float4* sample_buf, uint2* spill, unsigned spill_stride, unsigned* ctrl, unsigned long long* counters) {
+    hipLaunchKernelGGL((k_whitted<TRACE_BLOCK, TRACE_LDS>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, prm, pixel_xy, sample_index_tab, cur, n, sample_buf, spill,
+                       spill_stride, ctrl, counters);
+}
+unsigned whitted_max_depth() { return YK_WHITTED_MAX_DEPTH; }
 void launch_trace_any(hipStream_t s, unsigned grid, const DevScene& sc, const float4* shO, const float4* shD, const unsigned* slot_of,
                       const unsigned* count_ptr, unsigned* head, unsigned char* vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
                       unsigned long long* shadow_counter) {

@@ -294,6 +294,27 @@ def cornell_triangles_only():
     return s
 
 
+def glass_balls():
+    """Whitted test scene: the Cornell box with the copper sphere turned to glass, two more glass
+    spheres (one tinted, one with a different index, overlapping the glass box's shadow), a
+    point light beside the area light and a non-black background seen through the light hole —
+    nested reflection / transmission subtrees, total internal reflection inside the box, the
+    emitter seen through glass."""
+    s = cornell()
+    glass = len(s.materials) - 1
+    s.materials = list(s.materials) + [dict(kind=abi.MAT_GLASS, a=(0.9, 0.95, 1.0), b=(0.6, 0.9, 0.7), c=1.33), dict(kind=abi.MAT_GLASS, a=(1, 0.8, 0.7), b=(1, 1, 1), c=2.4)]
+    spheres = []
+    for (x, y, z), r, m in (((0.186, 0.082, -0.168), 0.082, glass), ((0.30, 0.40, -0.25), 0.06, glass + 1), ((0.40, 0.10, -0.12), 0.05, glass + 2)):
+        o2w, w2o = _translation((x, y, z))
+        spheres.append(dict(o2w=o2w, w2o=w2o, radius=r, material=m))
+    s.spheres = spheres
+    l2w, _ = _translation((0.45, 0.45, -0.05))
+    s.lights = list(s.lights) + [dict(kind="point", l2w=l2w, I=(0.05, 0.045, 0.04))]
+    s.background = (0.05, 0.07, 0.1)
+    s.name = "glass-balls"
+    return s
+
+
 # --------------------------------------------------------------------------- cfg 2: bunny-class mesh
 def _cube_sphere(n):
     """6 faces x n x n quads; returns unit-sphere points (nv,3) f64 and triangles (nt,3)."""
@@ -523,6 +544,8 @@ def by_name(name):
         return cornell()
     if name == "cornell-tris":
         return cornell_triangles_only()
+    if name == "glass-balls":
+        return glass_balls()
     if name == "cfg2":
         return bunny_class()
     if name == "cfg3":
