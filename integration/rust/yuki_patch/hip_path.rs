@@ -2,12 +2,13 @@
 //! libyuki_hip.so.  SOURCE ONLY (never compiled: no Rust toolchain in the build image).
 //!
 //! Upstream wiring:
-//!   integrators/mod.rs:33-40   add `HipPath(path::Params)` to `IntegratorType` (+ Display/EnumString)
-//!   integrators/mod.rs:43-52   `IntegratorType::HipPath(p) => Box::new(HipPath::new(p, hip_device()))`
+//!   integrators/mod.rs:33-40   add `HipPath(path::Params)` and `HipWhitted(whitted::Params)` to `IntegratorType` (+ Display/EnumString)
+//!   integrators/mod.rs:43-52   `IntegratorType::HipPath(p) => Box::new(HipPath::new(p, hip_device()))`,
+//!                              `IntegratorType::HipWhitted(p) => Box::new(HipPath::whitted(p, hip_device()))`
 //!   renderer/render_manager.rs build the `HipDevice` when a scene is loaded (see gpu_worker.rs)
 #![cfg(feature = "hip")]
 
-use super::{path, Integrator, RadianceResult};
+use super::{path, whitted, Integrator, RadianceResult};
 use crate::{
     camera::Camera,
     describe::{LightDesc, MaterialDesc, SamplerDesc, ShapeDesc, TextureDesc},
@@ -293,14 +294,23 @@ pub(crate) fn integrator_desc(p: &path::Params) -> sys::yk_integrator_desc {
     sys::yk_integrator_desc { kind: sys::YK_INTEGRATOR_PATH, max_depth: p.max_depth, has_clamp: p.indirect_clamp.is_some() as u32, indirect_clamp: p.indirect_clamp.unwrap_or(0.0) }
 }
 
+/// whitted.rs:17-25 (the device keeps at most 16 suspended calls: max_depth <= 16)
+pub(crate) fn whitted_desc(p: &whitted::Params) -> sys::yk_integrator_desc {
+    sys::yk_integrator_desc { kind: sys::YK_INTEGRATOR_WHITTED, max_depth: p.max_depth, has_clamp: 0, indirect_clamp: 0.0 }
+}
+
+/// Either device integrator: what differs is the `yk_integrator_desc` handed to the library.
 pub struct HipPath {
-    params: path::Params,
+    desc: sys::yk_integrator_desc,
     gpu: Arc<HipDevice>,
 }
 
 impl HipPath {
     pub fn new(params: path::Params, gpu: Arc<HipDevice>) -> Self {
-        Self { params, gpu }
+        Self { desc: integrator_desc(&params), gpu }
+    }
+    pub fn whitted(params: whitted::Params, gpu: Arc<HipDevice>) -> Self {
+        Self { desc: whitted_desc(&params), gpu }
     }
 }
 
@@ -326,7 +336,7 @@ impl Integrator for HipPath {
         if early_termination_predicate() {
             return 0;
         }
-        let (cam, smp, integ) = (camera_desc(camera), sampler_desc(sampler.as_ref()), integrator_desc(&self.params));
+        let (cam, smp, integ) = (camera_desc(camera), sampler_desc(sampler.as_ref()), self.desc);
         let t = sys::yk_tile { x0: tile.bb.p_min.x, y0: tile.bb.p_min.y, x1: tile.bb.p_max.x, y1: tile.bb.p_max.y };
         let mut stats = sys::yk_render_stats::default();
         // Spectrum<f32> is three packed f32 (math/spectrum.rs:45-55)
