@@ -4,7 +4,7 @@
 //   FilmSettings / FilmTile / film_tiles()     yuki/src/film.rs:14-65,409-475
 //   CameraParameters / FoV / Camera            yuki/src/camera.rs:19-114
 //   SamplerType::Uniform / ::Stratified        yuki/src/sampling/mod.rs:16-31
-//   IntegratorType::Path(PathParams)           yuki/src/integrators/mod.rs:33-53
+//   IntegratorType::{Path,Whitted,...}(params)  yuki/src/integrators/mod.rs:33-53
 //   Integrator::render(scene, camera, sampler, tile, tile_pixels) -> ray count
 //                                              yuki/src/integrators/mod.rs:120-185
 //   Scene                                      yuki/src/scene/mod.rs:41-49
@@ -94,7 +94,12 @@ struct PathParams {
     bool has_indirect_clamp = false;
     float indirect_clamp = 0.0f;
 };
+// integrators/whitted.rs:17-25
+struct WhittedParams {
+    uint32_t max_depth = 3;
+};
 struct IntegratorType {
+    static yk_integrator_desc Whitted(const WhittedParams& p = WhittedParams()) { return yk_integrator_desc{YK_INTEGRATOR_WHITTED, p.max_depth, 0u, 0.0f}; }
     static yk_integrator_desc Path(const PathParams& p = PathParams()) { return yk_integrator_desc{YK_INTEGRATOR_PATH, p.max_depth, p.has_indirect_clamp ? 1u : 0u, p.indirect_clamp}; }
     static yk_integrator_desc BVHIntersections() { return yk_integrator_desc{YK_INTEGRATOR_BVH_INTERSECTIONS, 1, 0, 0.0f}; }
     static yk_integrator_desc GeometryNormals() { return yk_integrator_desc{YK_INTEGRATOR_GEOMETRY_NORMALS, 1, 0, 0.0f}; }
