@@ -250,7 +250,8 @@ yk_status yk_film_update_tiles(const yk_tile* tiles, size_t n_tiles, const float
  * A scene (and a yk_tile_list) is read-only after creation and belongs to the DEVICE of `ctx`:
  * any context on that device may render it, also concurrently from several threads — two
  * contexts with their own streams keep two renders in flight, so the latency tail of one
- * overlaps the bulk of the next. */
+ * overlaps the bulk of the next.  Destroy it only after every render that uses
+ * it has completed (the library does not reference-count scenes). */
 yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* desc, yk_scene** out);
 void yk_scene_destroy(yk_scene* scene);
 yk_status yk_scene_get_info(const yk_scene* scene, yk_scene_info* out);
