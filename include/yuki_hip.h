@@ -304,6 +304,24 @@ yk_status yk_render_tile_list_device(yk_context* ctx, const yk_scene* scene, con
                                      yk_render_stats* stats, yk_cancel_fn cancel, void* user);
 yk_status yk_film_update_tile_list_device(yk_context* ctx, const yk_tile_list* list, const void* d_tile_rgb, uint16_t res_x, uint16_t res_y,
                                           void* d_film_rgb, void* stream, int accumulate);
+/* Several passes of the accumulating film in ONE submission: passes FilmTile.sample,
+ * FilmTile.sample + 1, ... + n_passes - 1 of every tile (what render_manager.rs:125-143 does by
+ * re-queueing the tiles n_passes times).  A single 1080p pass is 2 M camera rays — every launch
+ * of it lasts as long as its longest ray — so an interactive GPU worker renders a handful of
+ * passes per submission (8 passes: 2.6x the rays per second of pass-by-pass).
+ * out: n_passes x (pixels of the list) x RGB, pass-major; each pass is bit for bit what the
+ * one-pass call with that sample index returns.  yk_film_accumulate_tile_list_passes_device
+ * adds them to the film pass after pass (film.rs:260-272), so the film equals the one n_passes
+ * single submissions would have produced. */
+yk_status yk_render_tiles_accumulating_passes(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                              const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples,
+                                              size_t n_tiles, uint32_t n_passes, float* out_rgb, yk_render_stats* stats, yk_cancel_fn cancel,
+                                              void* user);
+yk_status yk_render_tile_list_passes_device(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                            const yk_integrator_desc* integrator, const yk_tile_list* list, uint32_t n_passes, void* d_out_rgb,
+                                            void* stream, yk_render_stats* stats, yk_cancel_fn cancel, void* user);
+yk_status yk_film_accumulate_tile_list_passes_device(yk_context* ctx, const yk_tile_list* list, const void* d_passes_rgb, uint32_t n_passes,
+                                                     uint16_t res_x, uint16_t res_y, void* d_film_rgb, void* stream);
 
 /* Film output (app/util.rs:90-111 write_exr -> exr::prelude::write_rgb_file): an OpenEXR 2
  * scan-line file with three FLOAT channels B, G, R, uncompressed, increasing Y — readable by

@@ -240,6 +240,9 @@ extern "C" {
     pub fn yk_tile_list_destroy(list: *mut yk_tile_list);
     pub fn yk_render_tile_list_device(ctx: *mut yk_context, scene: *const yk_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, list: *const yk_tile_list, d_out_rgb: *mut c_void, stream: *mut c_void, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
     pub fn yk_film_update_tile_list_device(ctx: *mut yk_context, list: *const yk_tile_list, d_tile_rgb: *const c_void, res_x: u16, res_y: u16, d_film_rgb: *mut c_void, stream: *mut c_void, accumulate: c_int) -> yk_status;
+    pub fn yk_render_tiles_accumulating_passes(ctx: *mut yk_context, scene: *const yk_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, tiles: *const yk_tile, tile_samples: *const u16, n_tiles: usize, n_passes: u32, out_rgb: *mut f32, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
+    pub fn yk_render_tile_list_passes_device(ctx: *mut yk_context, scene: *const yk_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, list: *const yk_tile_list, n_passes: u32, d_out_rgb: *mut c_void, stream: *mut c_void, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
+    pub fn yk_film_accumulate_tile_list_passes_device(ctx: *mut yk_context, list: *const yk_tile_list, d_passes_rgb: *const c_void, n_passes: u32, res_x: u16, res_y: u16, d_film_rgb: *mut c_void, stream: *mut c_void) -> yk_status;
     pub fn yk_write_exr(path: *const c_char, width: u32, height: u32, rgb: *const f32) -> yk_status;
     pub fn yk_write_pfm(path: *const c_char, width: u32, height: u32, rgb: *const f32) -> yk_status;
     pub fn yk_render_tile(ctx: *mut yk_context, scene: *const yk_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, tile: *const yk_tile, tile_pixels: *mut f32, out_rays: *mut u64) -> yk_status;

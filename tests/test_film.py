@@ -238,3 +238,53 @@ def test_context_stream_orders_foreign_work_after_a_render(ctx, yk):
         assert copy.cpu().numpy().tobytes() == want.tobytes()
         assert film.cpu().numpy().tobytes() == want_film.tobytes()
     ctx2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("integ_name,skind", [("path", "stratified"), ("path", "uniform"), ("whitted", "stratified")])
+def test_several_accumulating_passes_in_one_submission(ctx, yk, oracle, integ_name, skind):
+    """yk_render_tiles_accumulating_passes: passes s, s+1, ... rendered at once are bit for bit the
+    single-pass renders with those sample indices (and the oracle's), and the film accumulated from
+    them pass after pass equals the film of n separate submissions (film.rs:260-272)."""
+    import torch
+
+    sd = scenes.by_name("city-tiny" if integ_name == "path" else "glass-balls")
+    fs = yk.FilmSettings(res=(80, 48), tile_dim=16, accumulate=True)
+    cam = yk.Camera(sd.camera, fs)
+    tiles = yk.film_tiles(fs)
+    smp = yk.SamplerType.Stratified((3, 3), True, 0x73B9642E74AC471C) if skind == "stratified" else yk.SamplerType.Uniform(9, 0x73B9642E74AC471C)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=5)) if integ_name == "path" else yk.IntegratorType.Whitted(4)
+    it = yk.IntegratorType.instantiate(ctx, integ)
+    sc = yk.Scene(ctx, sd)
+    first = (np.arange(len(tiles)) % 3).astype(np.uint16)  # tiles at different sample counts, like a queue mid-way through a frame
+    n = 5
+    got, st = it.render_tiles_accumulating(sc, cam, smp, tiles, first, n_passes=n)
+    assert got.shape == (n, 80 * 48, 3)
+    osc = oracle.OracleScene(sd)
+    rays = 0
+    for k in range(n):
+        one, st1 = it.render_tiles_accumulating(sc, cam, smp, tiles, first + k)
+        assert got[k].tobytes() == one.tobytes()
+        rays += st1.rays
+        if k in (0, n - 1):
+            want, _ = osc.render_tiles_accumulating(cam.matrices, smp, integ, tiles, first + k)
+            assert got[k].tobytes() == want.tobytes()
+    assert st.rays == rays and st.samples == n * 80 * 48
+    # device film: one fused accumulate of n passes == n accumulates
+    tl = yk.TileList(ctx, tiles, first)
+    slab = torch.zeros(n * tl.n_pixels * 3, dtype=torch.float32, device="cuda:0")
+    film_a = torch.full((48 * 80 * 3,), 0.25, dtype=torch.float32, device="cuda:0")
+    film_b = film_a.clone()
+    it.render_tile_list_device(sc, cam, smp, tl, slab.data_ptr(), n_passes=n)
+    tl.update_film_device(slab.data_ptr(), fs.res, film_a.data_ptr(), accumulate=True, n_passes=n)
+    for k in range(n):
+        tl.update_film_device(slab.data_ptr() + 4 * 3 * tl.n_pixels * k, fs.res, film_b.data_ptr(), accumulate=True)
+    torch.cuda.synchronize()
+    assert slab.cpu().numpy().tobytes() == got.tobytes()
+    assert torch.equal(film_a, film_b)
+    host = np.full((48, 80, 3), 0.25, dtype=np.float32)
+    for k in range(n):
+        yk.accumulate_tiles(tiles, got[k], host)  # the host restatement of Film::update_tile, in place
+    assert film_a.cpu().numpy().tobytes() == host.tobytes()
+    with pytest.raises(yk.YukiError):
+        it.render_tiles_accumulating(sc, cam, smp, tiles, first, n_passes=70000)

@@ -114,6 +114,9 @@ SYMBOLS = {
     "yk_tile_list_destroy": (None, [vp]),
     "yk_render_tile_list_device": (C.c_int, [vp, vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), vp, vp, vp, C.POINTER(RenderStats), vp, vp]),
     "yk_film_update_tile_list_device": (C.c_int, [vp, vp, vp, C.c_uint16, C.c_uint16, vp, vp, C.c_int]),
+    "yk_render_tiles_accumulating_passes": (C.c_int, [vp, vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), vp, vp, C.c_size_t, C.c_uint32, vp, C.POINTER(RenderStats), vp, vp]),
+    "yk_render_tile_list_passes_device": (C.c_int, [vp, vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), vp, C.c_uint32, vp, vp, C.POINTER(RenderStats), vp, vp]),
+    "yk_film_accumulate_tile_list_passes_device": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint16, C.c_uint16, vp, vp]),
     "yk_write_exr": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, vp]),
     "yk_write_pfm": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, vp]),
 }

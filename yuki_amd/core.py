@@ -104,10 +104,16 @@ class TileList:
         self.h = h
         self.n_pixels = int(((self.tiles["x1"].astype(np.int64) - self.tiles["x0"]) * (self.tiles["y1"].astype(np.int64) - self.tiles["y0"])).sum())
 
-    def update_film_device(self, d_tile_rgb_ptr, res, d_film_ptr, stream=None, accumulate=False, ctx=None):
+    def update_film_device(self, d_tile_rgb_ptr, res, d_film_ptr, stream=None, accumulate=False, ctx=None, n_passes=1):
         """Film::update_tile for the whole list, device to device, enqueued on `stream` (default:
-        the stream of `ctx`, any context on the list's device; default the one that made it)."""
+        the stream of `ctx`, any context on the list's device; default the one that made it).
+        n_passes > 1: `d_tile_rgb_ptr` holds that many passes (pass-major), added one after the other."""
         c = ctx or self.ctx
+        if n_passes != 1:
+            if not accumulate:
+                raise ValueError("several passes only make sense for the accumulating film")
+            check(lib().yk_film_accumulate_tile_list_passes_device(c.h, self.h, C.c_void_p(d_tile_rgb_ptr), n_passes, res[0], res[1], C.c_void_p(d_film_ptr), C.c_void_p(stream) if stream else None), c.h)
+            return
         check(lib().yk_film_update_tile_list_device(c.h, self.h, C.c_void_p(d_tile_rgb_ptr), res[0], res[1], C.c_void_p(d_film_ptr), C.c_void_p(stream) if stream else None, 1 if accumulate else 0), c.h)
 
     def close(self):
@@ -333,17 +339,25 @@ class Integrator:
         )
         return out, stats
 
-    def render_tiles_accumulating(self, scene, camera, sampler, tiles, tile_samples, cancel=None):
+    def render_tiles_accumulating(self, scene, camera, sampler, tiles, tile_samples, cancel=None, n_passes=1):
         """Integrator::render(accumulating=true) (integrators/mod.rs:146-161) for a list of
-        (tile, FilmTile.sample) pairs: one sample per pixel, raw value.  Returns (rgb, stats)."""
+        (tile, FilmTile.sample) pairs: one sample per pixel, raw value.  Returns (rgb, stats);
+        n_passes > 1 renders passes sample .. sample + n_passes - 1 at once: rgb is (n_passes, pixels, 3)."""
         tiles = np.ascontiguousarray(tiles, dtype=abi.TILE_DTYPE)
         ts = np.ascontiguousarray(tile_samples, dtype=np.uint16)
         if len(ts) != len(tiles):
             raise ValueError("one sample index per tile")
         npx = int(((tiles["x1"].astype(np.int64) - tiles["x0"]) * (tiles["y1"].astype(np.int64) - tiles["y0"])).sum())
-        out = np.zeros((npx, 3), dtype=np.float32)
         stats = RenderStats()
         cb = _ffi.CANCEL_FN(lambda _u: 1 if cancel() else 0) if cancel else None
+        if n_passes != 1:
+            out = np.zeros((n_passes, npx, 3), dtype=np.float32)
+            check(
+                lib().yk_render_tiles_accumulating_passes(self.ctx.h, scene.h, C.byref(camera.matrices), C.byref(sampler), C.byref(self.desc), _p(tiles), _p(ts), len(tiles), n_passes, _p(out), C.byref(stats), C.cast(cb, C.c_void_p) if cb else None, None),
+                self.ctx.h,
+            )
+            return out, stats
+        out = np.zeros((npx, 3), dtype=np.float32)
         check(
             lib().yk_render_tiles_accumulating(self.ctx.h, scene.h, C.byref(camera.matrices), C.byref(sampler), C.byref(self.desc), _p(tiles), _p(ts), len(tiles), _p(out), C.byref(stats), C.cast(cb, C.c_void_p) if cb else None, None),
             self.ctx.h,
@@ -360,10 +374,17 @@ class Integrator:
         )
         return stats
 
-    def render_tile_list_device(self, scene, camera, sampler, tile_list, d_out_ptr, stream=None, want_stats=False):
+    def render_tile_list_device(self, scene, camera, sampler, tile_list, d_out_ptr, stream=None, want_stats=False, n_passes=1):
         """Render a prepared TileList into HBM at `d_out_ptr`; with want_stats=False the call only
-        enqueues work on `stream` (no host synchronisation)."""
+        enqueues work on `stream` (no host synchronisation).  n_passes > 1 (accumulating list):
+        that many passes at once, pass-major in `d_out_ptr`."""
         stats = RenderStats()
+        if n_passes != 1:
+            check(
+                lib().yk_render_tile_list_passes_device(self.ctx.h, scene.h, C.byref(camera.matrices), C.byref(sampler), C.byref(self.desc), tile_list.h, n_passes, C.c_void_p(d_out_ptr), C.c_void_p(stream) if stream else None, C.byref(stats) if want_stats else None, None, None),
+                self.ctx.h,
+            )
+            return stats if want_stats else None
         check(
             lib().yk_render_tile_list_device(self.ctx.h, scene.h, C.byref(camera.matrices), C.byref(sampler), C.byref(self.desc), tile_list.h, C.c_void_p(d_out_ptr), C.c_void_p(stream) if stream else None, C.byref(stats) if want_stats else None, None, None),
             self.ctx.h,

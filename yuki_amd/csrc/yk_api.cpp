@@ -852,6 +852,7 @@ static yk_status make_params(yk_context* ctx, const yk_sampler_desc* smp, const 
     uint64_t spp = (uint64_t)prm.sampler.nx * prm.sampler.ny;
     if (spp > 0xFFFFu) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "samples per pixel exceed u16 (integrators/mod.rs:139)");
     prm.sampler.spp = (unsigned)spp;
+    prm.spe = (unsigned)spp;  // plain film: every sample of the pixel (callers with a sample-index table overwrite it)
     prm.max_depth = integ->max_depth;
     prm.has_clamp = integ->has_clamp;
     prm.clamp = integ->indirect_clamp;
@@ -982,7 +983,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
 static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
                                    const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
                                    void* d_out_rgb, void* stream, yk_render_stats* stats, yk_cancel_fn cancel, void* user,
-                                   const yk_tile_list* prepared = nullptr) {
+                                   const yk_tile_list* prepared = nullptr, uint32_t n_passes = 1) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (prepared) {
@@ -1027,7 +1028,10 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         off[t + 1] = (uint32_t)total_px;
     }
     const bool accumulating = tile_samples != nullptr;
-    const uint32_t spp = accumulating ? 1u : prm.sampler.spp;  // samples rendered per pixel by this call
+    if (n_passes == 0 || n_passes > 0xFFFFu || (!accumulating && n_passes != 1)) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "bad number of passes");
+    // samples rendered per pixel by this call: the accumulating film renders passes FilmTile.sample .. + n_passes - 1
+    const uint32_t spp = accumulating ? n_passes : prm.sampler.spp;
+    prm.spe = spp;
     // chunk so that sample ids fit u32 and the sample buffer stays under the cap
     uint64_t max_px_chunk = std::min<uint64_t>(0xFFFFFFF0ull / spp, (uint64_t)ctx->sample_buf_cap / (16ull * spp));
     if (max_px_chunk == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "sample_buf_cap too small for one pixel");
@@ -1168,7 +1172,10 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
             HIP_TRY(ctx, hipEventRecord(ctx->ws[1].done, ctx->ws[1].stream));
             HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ws[1].done, 0));
         }
-        launch_resolve(st, sample_buf, npx, spp, out + 3 * (size_t)px0);
+        if (accumulating)  // raw values, pass-major over the whole tile list
+            launch_resolve_passes(st, sample_buf, npx, spp, out + 3 * (size_t)px0, 3 * (size_t)total_px);
+        else
+            launch_resolve(st, sample_buf, npx, spp, out + 3 * (size_t)px0);
         t_begin = t_end;
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1204,7 +1211,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
 
 static yk_status render_tiles_host(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
                                    const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
-                                   float* out_rgb, yk_render_stats* stats, yk_cancel_fn cancel, void* user);
+                                   float* out_rgb, yk_render_stats* stats, yk_cancel_fn cancel, void* user, uint32_t n_passes = 1);
 
 extern "C" {
 
@@ -1230,6 +1237,15 @@ yk_status yk_render_tiles_accumulating(yk_context* ctx, const yk_scene* scene, c
     YK_LOCK(ctx);
     if (!tile_samples) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null tile_samples");
     return render_tiles_host(ctx, scene, camera, sampler, integrator, tiles, tile_samples, n_tiles, out_rgb, stats, cancel, user);
+}
+
+yk_status yk_render_tiles_accumulating_passes(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                              const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
+                                              uint32_t n_passes, float* out_rgb, yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
+    if (!tile_samples) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null tile_samples");
+    return render_tiles_host(ctx, scene, camera, sampler, integrator, tiles, tile_samples, n_tiles, out_rgb, stats, cancel, user, n_passes);
 }
 
 yk_status yk_tile_list_create(yk_context* ctx, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles, yk_tile_list** out) {
@@ -1306,8 +1322,31 @@ yk_status yk_render_tile_list_device(yk_context* ctx, const yk_scene* scene, con
                              user, list);
 }
 
+yk_status yk_render_tile_list_passes_device(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                            const yk_integrator_desc* integrator, const yk_tile_list* list, uint32_t n_passes, void* d_out_rgb, void* stream,
+                                            yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!list) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null tile list");
+    if (list->samples.empty()) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "passes need an accumulating tile list (tile_samples)");
+    return render_tiles_impl(ctx, scene, camera, sampler, integrator, list->tiles.data(), nullptr, list->tiles.size(), d_out_rgb, stream, stats, cancel,
+                             user, list, n_passes);
+}
+
+static yk_status film_update_list(yk_context* ctx, const yk_tile_list* list, const void* d_tile_rgb, uint16_t res_x, uint16_t res_y, void* d_film_rgb,
+                                  void* stream, int accumulate, uint32_t n_passes);
+
+yk_status yk_film_accumulate_tile_list_passes_device(yk_context* ctx, const yk_tile_list* list, const void* d_passes_rgb, uint32_t n_passes, uint16_t res_x,
+                                                     uint16_t res_y, void* d_film_rgb, void* stream) {
+    return film_update_list(ctx, list, d_passes_rgb, res_x, res_y, d_film_rgb, stream, 1, n_passes);
+}
+
 yk_status yk_film_update_tile_list_device(yk_context* ctx, const yk_tile_list* list, const void* d_tile_rgb, uint16_t res_x, uint16_t res_y,
                                           void* d_film_rgb, void* stream, int accumulate) {
+    return film_update_list(ctx, list, d_tile_rgb, res_x, res_y, d_film_rgb, stream, accumulate, 1);
+}
+
+static yk_status film_update_list(yk_context* ctx, const yk_tile_list* list, const void* d_tile_rgb, uint16_t res_x, uint16_t res_y, void* d_film_rgb,
+                                  void* stream, int accumulate, uint32_t n_passes) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (!list || !d_tile_rgb || !d_film_rgb) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
@@ -1316,8 +1355,9 @@ yk_status yk_film_update_tile_list_device(yk_context* ctx, const yk_tile_list* l
         if (t.x1 > res_x || t.y1 > res_y) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "update_tile: Tile doesn't fit film");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (n_passes == 0 || n_passes > 0xFFFFu) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "bad number of passes");
     launch_film_scatter(st, list->pixel_xy.as<uint32_t>(), list->off.back(), reinterpret_cast<const float*>(d_tile_rgb), res_x,
-                        reinterpret_cast<float*>(d_film_rgb), accumulate ? 1 : 0);
+                        reinterpret_cast<float*>(d_film_rgb), accumulate ? 1 : 0, n_passes, 3 * (size_t)list->off.back());
     HIP_TRY(ctx, hipGetLastError());
     return YK_OK;  // asynchronous: ordered on `stream`
 }
@@ -1332,7 +1372,7 @@ yk_status yk_render_tiles(yk_context* ctx, const yk_scene* scene, const yk_camer
 
 static yk_status render_tiles_host(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
                                    const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
-                                   float* out_rgb, yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
+                                   float* out_rgb, yk_render_stats* stats, yk_cancel_fn cancel, void* user, uint32_t n_passes) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (!tiles || n_tiles == 0 || !out_rgb) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
@@ -1342,12 +1382,13 @@ static yk_status render_tiles_host(yk_context* ctx, const yk_scene* scene, const
         total_px += (uint64_t)(tiles[t].x1 - tiles[t].x0) * (uint64_t)(tiles[t].y1 - tiles[t].y0);
     }
     (void)hipSetDevice(ctx->device);
-    HIP_TRY(ctx, ctx->scratch[0].ensure(total_px * 12));
+    if (n_passes == 0 || n_passes > 0xFFFFu) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "bad number of passes");
+    HIP_TRY(ctx, ctx->scratch[0].ensure(total_px * 12 * n_passes));
     yk_render_stats local;
     yk_status st = render_tiles_impl(ctx, scene, camera, sampler, integrator, tiles, tile_samples, n_tiles, ctx->scratch[0].p, nullptr,
-                                     stats ? stats : &local, cancel, user);
+                                     stats ? stats : &local, cancel, user, nullptr, n_passes);
     if (st != YK_OK) return st;
-    HIP_TRY(ctx, hipMemcpy(out_rgb, ctx->scratch[0].p, total_px * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out_rgb, ctx->scratch[0].p, total_px * 12 * n_passes, hipMemcpyDeviceToHost));
     return YK_OK;
 }
 
@@ -1425,6 +1466,7 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
     if (ps != YK_OK) return ps;
     if (prm.integrator != YK_INTEGRATOR_PATH && prm.integrator != YK_INTEGRATOR_WHITTED)
         return fail(ctx, YK_ERR_UNSUPPORTED, "yk_li implements the Path and Whitted integrators");
+    prm.spe = 1;  // one table entry (pixel, sample index) per ray
     if (prm.max_depth > YK_CTRL_MAX_DEPTH) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "max_depth too large");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;

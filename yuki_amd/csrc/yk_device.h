@@ -158,6 +158,10 @@ struct RenderParams {
     uint32_t has_clamp;
     float clamp;
     uint32_t integrator;  // yk_integrator_kind
+    // Samples rendered per entry of the call's pixel table: sample id = entry * spe + k.  Plain
+    // film: spe = spp and sample index = k.  With a sample-index table (accumulating film,
+    // yk_li) the sample index is table[entry] + k; spe = the number of passes rendered at once.
+    uint32_t spe;
 };
 
 }  // namespace yk

@@ -38,7 +38,9 @@ void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const Render
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
                        const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* bc);
 void launch_resolve(hipStream_t s, const float4* sample_buf, uint32_t n_pixels, uint32_t spp, float* out_rgb);
-void launch_film_scatter(hipStream_t s, const uint32_t* pixel_xy, uint32_t n_pixels, const float* tile_rgb, uint32_t res_x, float* film_rgb, int accumulate = 0);
+void launch_resolve_passes(hipStream_t s, const float4* sample_buf, uint32_t n_pixels, uint32_t n_passes, float* out_rgb, size_t pass_stride);
+void launch_film_scatter(hipStream_t s, const uint32_t* pixel_xy, uint32_t n_pixels, const float* tile_rgb, uint32_t res_x, float* film_rgb, int accumulate,
+                         uint32_t n_passes = 1, size_t pass_stride = 0);
 void launch_debug_shade(hipStream_t s, const DevScene& sc, uint32_t integrator, PathBuffers cur, const int* hit_tri, const uint4* stats, uint32_t n,
                         float4* sample_buf);
 void launch_device_math(hipStream_t s, int fn, size_t n, const float* a, const float* b, float* out);

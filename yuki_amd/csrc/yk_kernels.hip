@@ -56,7 +56,7 @@ __device__ __forceinline__ void camera_ray(const DevCamera& cam, float fx, float
     d = xf_vector(cam.c2w, dir);
 }
 
-// `pixel_sample` != null: the accumulating film (integrators/mod.rs:146-161) — ONE sample per
+// `pixel_sample` != null: the accumulating film (integrators/mod.rs:146-161) — prm.spe passes of ONE sample per
 // pixel whose global index is the tile's FilmTile.sample; otherwise all spp samples.
 __global__ void k_raygen(DevCamera cam, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* pixel_sample, uint64_t work0, uint32_t n,
                          PathBuffers out, float4* sample_buf, unsigned* count) {
@@ -64,15 +64,8 @@ __global__ void k_raygen(DevCamera cam, RenderParams prm, const uint32_t* pixel_
     if (i == 0) *count = n;
     if (i >= n) return;
     uint64_t w = work0 + i;
-    uint32_t spp = prm.sampler.spp;
-    uint32_t pix, s;
-    if (pixel_sample) {
-        pix = (uint32_t)w;
-        s = pixel_sample[pix];
-    } else {
-        pix = (uint32_t)(w / spp);
-        s = (uint32_t)(w % spp);
-    }
+    const uint32_t pix = (uint32_t)(w / prm.spe);
+    const uint32_t s = (pixel_sample ? pixel_sample[pix] : 0u) + (uint32_t)(w % prm.spe);
     uint32_t xy = pixel_xy[pix];
     uint32_t px = xy & 0xffffu, py = xy >> 16;
     SamplerState st = sampler_start(prm.sampler, px, py, s, 0);
@@ -269,10 +262,11 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
             st.rng.inc = (u64)r.z | ((u64)r.w << 32);
             st.dimension = __float_as_uint(c.w);
             // film renders: sample_id = pixel*spp + sample ; yk_li: one table entry per ray
-            uint32_t xy = pixel_xy[sample_index_tab ? sid : sid / prm.sampler.spp];
+            const uint32_t pix = sid / prm.spe;  // entry of the pixel table (yk_device.h: RenderParams::spe)
+            uint32_t xy = pixel_xy[pix];
             st.px = xy & 0xffffu;
             st.py = xy >> 16;
-            st.sample_index = sample_index_tab ? sample_index_tab[sid] : sid % prm.sampler.spp;
+            st.sample_index = (sample_index_tab ? sample_index_tab[pix] : 0u) + sid % prm.spe;
             int tri = hit_tri[i];
             hit = tri >= 0;
             if (hit) {
@@ -463,16 +457,38 @@ __global__ void k_resolve(const float4* sample_buf, uint32_t n_pixels, uint32_t 
     out_rgb[3 * (size_t)p + 2] = color.b;
 }
 
+// Accumulating film, `n_passes` passes rendered at once: the raw value of every (pass, pixel),
+// pass-major — what n_passes calls of Integrator::render(accumulating = true) with
+// FilmTile.sample, sample + 1, ... would have written (integrators/mod.rs:146-161).
+__global__ void k_resolve_passes(const float4* sample_buf, uint32_t n_pixels, uint32_t n_passes, float* out_rgb, size_t pass_stride) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_pixels * n_passes) return;
+    const uint32_t p = (uint32_t)(i / n_passes), k = (uint32_t)(i % n_passes);
+    const float4 v = sample_buf[i];
+    float* o = out_rgb + (size_t)k * pass_stride + 3 * (size_t)p;
+    o[0] = v.x;
+    o[1] = v.y;
+    o[2] = v.z;
+}
+
 // Film::update_tile on the device (film.rs:236-278): tile-major -> row-major film
-__global__ void k_film_scatter(const uint32_t* pixel_xy, uint32_t n_pixels, const float* tile_rgb, uint32_t res_x, float* film_rgb, int accumulate) {
+__global__ void k_film_scatter(const uint32_t* pixel_xy, uint32_t n_pixels, const float* tile_rgb, uint32_t res_x, float* film_rgb, int accumulate,
+                               uint32_t n_passes, size_t pass_stride) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pixels) return;
     uint32_t xy = pixel_xy[p];
     size_t dst = (size_t)(xy >> 16) * res_x + (xy & 0xffffu);
-    if (accumulate) {  // film.rs:260-272: *fc += c
-        film_rgb[3 * dst + 0] += tile_rgb[3 * (size_t)p + 0];
-        film_rgb[3 * dst + 1] += tile_rgb[3 * (size_t)p + 1];
-        film_rgb[3 * dst + 2] += tile_rgb[3 * (size_t)p + 2];
+    if (accumulate) {  // film.rs:260-272: *fc += c, one pass after the other
+        float r = film_rgb[3 * dst + 0], g = film_rgb[3 * dst + 1], b = film_rgb[3 * dst + 2];
+        for (uint32_t k = 0; k < n_passes; ++k) {
+            const float* t = tile_rgb + (size_t)k * pass_stride + 3 * (size_t)p;
+            r += t[0];
+            g += t[1];
+            b += t[2];
+        }
+        film_rgb[3 * dst + 0] = r;
+        film_rgb[3 * dst + 1] = g;
+        film_rgb[3 * dst + 2] = b;
         return;
     }
     film_rgb[3 * dst + 0] = tile_rgb[3 * (size_t)p + 0];
@@ -617,9 +633,14 @@ void launch_resolve(hipStream_t s, const float4* sample_buf, uint32_t n_pixels, 
     if (!n_pixels) return;
     hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, sample_buf, n_pixels, spp, out_rgb);
 }
-void launch_film_scatter(hipStream_t s, const uint32_t* pixel_xy, uint32_t n_pixels, const float* tile_rgb, uint32_t res_x, float* film_rgb, int accumulate) {
+void launch_resolve_passes(hipStream_t s, const float4* sample_buf, uint32_t n_pixels, uint32_t n_passes, float* out_rgb, size_t pass_stride) {
     if (!n_pixels) return;
-    hipLaunchKernelGGL(k_film_scatter, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, pixel_xy, n_pixels, tile_rgb, res_x, film_rgb, accumulate);
+    hipLaunchKernelGGL(k_resolve_passes, dim3(blocks_for((size_t)n_pixels * n_passes, 256)), dim3(256), 0, s, sample_buf, n_pixels, n_passes, out_rgb, pass_stride);
+}
+void launch_film_scatter(hipStream_t s, const uint32_t* pixel_xy, uint32_t n_pixels, const float* tile_rgb, uint32_t res_x, float* film_rgb, int accumulate,
+                         uint32_t n_passes, size_t pass_stride) {
+    if (!n_pixels) return;
+    hipLaunchKernelGGL(k_film_scatter, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, pixel_xy, n_pixels, tile_rgb, res_x, film_rgb, accumulate, n_passes, pass_stride);
 }
 void launch_debug_shade(hipStream_t s, const DevScene& sc, uint32_t integrator, PathBuffers cur, const int* hit_tri, const uint4* stats, uint32_t n,
                         float4* sample_buf) {
