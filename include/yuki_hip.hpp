@@ -197,13 +197,14 @@ class Integrator {
         return st;
     }
 
-    // Integrator::render(accumulating = true): one sample (global index tile_samples[t]) per pixel, raw value
+    // Integrator::render(accumulating = true): one sample (global index tile_samples[t]) per pixel, raw value;
+    // n_passes > 1 renders samples tile_samples[t] .. + n_passes - 1 at once (out_rgb: n_passes x pixels x RGB, pass-major)
     yk_render_stats render_tiles_accumulating(const Scene& scene, const Camera& camera, const yk_sampler_desc& sampler, const std::vector<FilmTile>& tiles,
-                                              const std::vector<uint16_t>& tile_samples, float* out_rgb) const {
+                                              const std::vector<uint16_t>& tile_samples, float* out_rgb, uint32_t n_passes = 1) const {
         if (tile_samples.size() != tiles.size()) throw Error(YK_ERR_INVALID_ARGUMENT, "one sample index per tile");
         yk_render_stats st{};
-        check(yk_render_tiles_accumulating(ctx_.handle(), scene.handle(), &camera.matrices, &sampler, &desc_, tiles.data(), tile_samples.data(), tiles.size(), out_rgb, &st,
-                                           nullptr, nullptr),
+        check(yk_render_tiles_accumulating_passes(ctx_.handle(), scene.handle(), &camera.matrices, &sampler, &desc_, tiles.data(), tile_samples.data(), tiles.size(), n_passes,
+                                                  out_rgb, &st, nullptr, nullptr),
               ctx_.handle());
         return st;
     }
