@@ -898,13 +898,22 @@ struct KernelTimer {
 // one batch of `n` paths already generated into buffer 0; runs the bounce loop
 static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* scene, const RenderParams& prm, const uint32_t* pixel_xy,
                         const uint32_t* sample_index_tab, float4* sample_buf, KernelTimer& kt, unsigned long long* counters, bool coherent,
-                        uint32_t* n_shadow_launches = nullptr) {
+                        uint32_t n_paths, uint32_t* n_shadow_launches = nullptr) {
     unsigned* ctrl = ws.ctrl.as<unsigned>();
     const DevScene& ds = scene->dev;
-    const unsigned tg = trace_grid(ctx);
-    const unsigned pg = (unsigned)ctx->n_cu * packet_blocks_per_cu();
+    // Queue lengths are only known on the device, but none exceeds the batch's path count
+    // (x lights for shadow rays).  A small job — one 16x16 tile of the reference's per-tile
+    // calls is 16 K paths — gets grids of that size instead of machine-filling ones: every wave
+    // of a persistent kernel pays one atomic on the queue head before it can find out that
+    // there is nothing for it (7168 waves x 8 bounces x 3 kernels per tile otherwise).
+    auto fit = [](unsigned full, uint64_t items) { return (unsigned)std::min<uint64_t>(full, std::max<uint64_t>(1, (items + 255) / 256)); };
+    const uint64_t n_shadow_max = (uint64_t)n_paths * std::max(1u, scene->n_lights);
+    const unsigned tg = fit(trace_grid(ctx), n_paths), tg_any = fit(trace_grid(ctx), n_shadow_max);
+    const unsigned pg_full = (unsigned)ctx->n_cu * packet_blocks_per_cu();
+    const unsigned pg = fit(pg_full, n_paths), pg_any = fit(pg_full, n_shadow_max);
     static const unsigned shade_bpc = std::getenv("YK_SHADE_BPC") ? (unsigned)std::atoi(std::getenv("YK_SHADE_BPC")) : 8u;
-    const unsigned sg = (unsigned)ctx->n_cu * shade_bpc;
+    const unsigned sg = fit((unsigned)ctx->n_cu * shade_bpc, n_paths);
+    const unsigned spill_stride = trace_grid(ctx) * trace_block_size();
     unsigned cur = 0;
     // Bounce b: trace_closest -> shade on `st`; then {trace_any, accumulate}(b) go to the side
     // stream while `st` already traces bounce b+1 — two persistent kernels whose drained
@@ -929,7 +938,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
             launch_trace_closest_packet(st, pg, ds, pc.rayO, pc.rayD, bc, bc + YK_CTRL_HEAD, ws.hit.as<int>(), counters);
         else
             launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, bc, bc + YK_CTRL_HEAD, ws.hit.as<int>(), nullptr, nullptr,
-                                 ws.spill.as<uint2>(), tg * trace_block_size(), ctrl, counters);
+                                 ws.spill.as<uint2>(), spill_stride, ctrl, counters);
         kt.end(e, 0, st);
         if (overlap && b > 0) (void)hipStreamWaitEvent(st, ws.ev_acc, 0);
         e = kt.begin(st);
@@ -944,14 +953,14 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         e = kt.begin(sb);
         uint2* any_spill = (overlap ? ws.spill_side : ws.spill).as<uint2>();
         if (all_delta) {
-            launch_trace_any_packet(sb, pg, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), bc + YK_CTRL_SHQ,
+            launch_trace_any_packet(sb, pg_any, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), bc + YK_CTRL_SHQ,
                                     bc + YK_CTRL_HEAD + 1, ws.vis.as<unsigned char>(), counters + 1);
         } else {
-            launch_trace_any(sb, tg, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), bc + YK_CTRL_SHQ,
-                             bc + YK_CTRL_HEAD + 1, ws.vis.as<unsigned char>(), any_spill, tg * trace_block_size(), ctrl, counters + 1);
+            launch_trace_any(sb, tg_any, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), bc + YK_CTRL_SHQ,
+                             bc + YK_CTRL_HEAD + 1, ws.vis.as<unsigned char>(), any_spill, spill_stride, ctrl, counters + 1);
             if (split && n_shadow_launches) ++*n_shadow_launches;
             if (split)  // rays converging on a point / spot / distant light: wave packets
-                launch_trace_any_packet(sb, pg, ds, ws.shO2.as<float4>(), ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc + YK_CTRL_SHQ2,
+                launch_trace_any_packet(sb, pg_any, ds, ws.shO2.as<float4>(), ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc + YK_CTRL_SHQ2,
                                         bc + YK_CTRL_HEAD + 2, ws.vis.as<unsigned char>(), counters + 1);
         }
         kt.end(e, 1, sb);
@@ -1146,7 +1155,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
             launch_raygen(bs, cam, prm, pixel_xy, pixel_sample, w0, n, path_buffers(ws, 0), sample_buf, ctrl + YK_CTRL_BOUNCE(0));
             ++n_batches;
             if (is_path) {
-                run_bounces(ctx, ws, bs, scene, prm, pixel_xy, pixel_sample, sample_buf, kt, counters, true, &n_shadow);
+                run_bounces(ctx, ws, bs, scene, prm, pixel_xy, pixel_sample, sample_buf, kt, counters, true, n, &n_shadow);
                 n_trace += prm.max_depth;
             } else if (prm.integrator == YK_INTEGRATOR_WHITTED) {
                 // one lane per camera sample runs the whole recursion (whitted.rs:74-181)
@@ -1496,7 +1505,7 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
         launch_whitted(st, trace_grid(ctx), scene->dev, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), path_buffers(ctx->ws[0], 0), (uint32_t)n,
                        ctx->sample_buf.as<float4>(), ctx->ws[0].spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), ctrl, counters);
     else
-        run_bounces(ctx, ctx->ws[0], st, scene, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), ctx->sample_buf.as<float4>(), kt, counters, false);
+        run_bounces(ctx, ctx->ws[0], st, scene, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), ctx->sample_buf.as<float4>(), kt, counters, false, (uint32_t)n);
     HIP_TRY(ctx, hipGetLastError());
     std::vector<float> tmp(n * 4);
     HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->sample_buf.p, n * 16, hipMemcpyDeviceToHost, st));
