@@ -315,26 +315,40 @@ template <int BLOCK, int LDS_DEPTH> __device__ __forceinline__ bool pop_closest(
 // Wave-local work distribution: claims CHUNK indices at a time from *head.
 struct ChunkCursor {
     unsigned cur, end;  // wave-uniform
-    bool exhausted;
+    bool exhausted, took_share;
     __device__ __forceinline__ void init() {
         cur = end = 0;
-        exhausted = false;
+        exhausted = took_share = false;
     }
     // hands `want` lanes consecutive indices; returns the index of this lane or
     // 0xffffffff.  All lanes of the wave call it (converged).
-    // The chunk shrinks for short queues (late bounces, small per-GPU shares) so that
-    // the rays spread over all resident waves instead of a few waves running
-    // several rounds: chunk = clamp(n / waves_in_grid, 8, CHUNK).
+    // Long queues: CHUNK indices per claim, one atomic on *head each.  A queue that one chunk
+    // per wave covers (n <= waves * CHUNK: late bounces, small per-GPU shares, interactive
+    // passes) is cut into equal shares instead, wave w takes share w and nothing else: the
+    // two atomics per wave of the dynamic scheme (a claim and a failed claim, ~14 K per launch on
+    // one address at ~100 M/s) were most of what such a launch cost beyond its longest ray.
     template <int CHUNK> __device__ __forceinline__ unsigned take(bool want, unsigned n, unsigned* head) {
         unsigned long long mask = __ballot(want);
         if (mask == 0ull || exhausted) return 0xffffffffu;
         if (cur >= end) {
             const unsigned waves = gridDim.x * (blockDim.x / YK_WAVE);
-            unsigned chunk = n / waves;
-            chunk = chunk < 8u ? 8u : (chunk > (unsigned)CHUNK ? (unsigned)CHUNK : chunk);
-            unsigned base = 0;
-            if (lane_id() == 0) base = atomicAdd(head, chunk);
-            base = __shfl(base, 0);
+            unsigned base;
+            unsigned chunk;
+            if (n <= waves * (unsigned)CHUNK) {
+                if (took_share) {
+                    exhausted = true;
+                    return 0xffffffffu;
+                }
+                took_share = true;
+                chunk = (n + waves - 1u) / waves;
+                chunk = chunk < 8u ? 8u : chunk;  // fewer, fuller waves for very short queues
+                base = (blockIdx.x * (blockDim.x / YK_WAVE) + threadIdx.x / YK_WAVE) * chunk;
+            } else {
+                chunk = (unsigned)CHUNK;
+                base = 0;
+                if (lane_id() == 0) base = atomicAdd(head, chunk);
+                base = __shfl(base, 0);
+            }
             if (base >= n) {
                 exhausted = true;
                 return 0xffffffffu;
