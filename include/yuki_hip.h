@@ -219,7 +219,8 @@ yk_status yk_last_error(const yk_context* ctx, char* buf, size_t cap);
  * Owned by the context; NULL for a NULL context. */
 void* yk_context_stream(const yk_context* ctx);
 /* tuning knobs (none changes any result): "batch_paths" (camera samples per batch),
- * "streams" (1|2 work sets), "sample_buf_cap" (bytes), "time_kernels" (0|1),
+ * "streams" (1|2 work sets), "sample_buf_cap" (bytes), "time_kernels" (0 | 1: per-kernel
+ * seconds in yk_render_stats for jobs of at least 2^20 samples | 2: always),
  * "packet_bounces" / "packet_shadow_bounces" (leading bounces traced by the wave-packet
  * kernels), "overlap_shadow" (0|1), "shade_reorder" (0|1: paths of a shade block dealt to
  * lanes by material kind), "top_nodes" (tree-top nodes the traversal kernels keep

@@ -5,6 +5,8 @@ import sys, time, threading
 sys.path.insert(0, ".")
 import numpy as np
 from yuki_amd import scenes, core as yk
+import os
+OPTS = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("YK_OPTS", "").split(",") if kv)}  # e.g. YK_OPTS=overlap_shadow=0
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 sd = scenes.by_name("cfg3")
@@ -12,14 +14,14 @@ fs = yk.FilmSettings(res=(1920, 1080))
 tiles = yk.film_tiles(fs)[:N]
 smp = yk.SamplerType.Stratified((8, 8), True)
 integ = yk.IntegratorType.Path(yk.PathParams(max_depth=8))
-ctx0 = yk.Context(0)
+ctx0 = yk.Context(0, **OPTS)
 sc = yk.Scene(ctx0, sd)
 cam = yk.Camera(sd.camera, fs)
 ref, st = yk.IntegratorType.instantiate(ctx0, integ).render_tiles(sc, cam, smp, tiles)
 print(f"one batched call: {st.rays} rays in {st.seconds_total*1e3:.1f} ms = {st.rays/st.seconds_total*1e-6:.0f} Mray/s")
 offs = np.concatenate([[0], np.cumsum((tiles["x1"].astype(int) - tiles["x0"]) * (tiles["y1"].astype(int) - tiles["y0"]))])
 for T in (1, 4, 15):
-    ctxs = [yk.Context(0) for _ in range(T)]
+    ctxs = [yk.Context(0, **OPTS) for _ in range(T)]
     its = [yk.IntegratorType.instantiate(c, integ) for c in ctxs]
     out = np.zeros_like(ref)
     rays = [0] * T

@@ -7,6 +7,8 @@ sys.path.insert(0, ".")
 import numpy as np
 import torch
 from yuki_amd import scenes, core as yk
+import os
+OPTS = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("YK_OPTS", "").split(",") if kv)}  # e.g. YK_OPTS=overlap_shadow=0
 
 TOTAL = int(sys.argv[1]) if len(sys.argv) > 1 else 32  # passes per measurement
 sd = scenes.by_name("cfg3")
@@ -15,7 +17,7 @@ tiles = yk.film_tiles(fs)
 smp = yk.SamplerType.Stratified((8, 8), True)
 dev = torch.device("cuda:0")
 integ = yk.IntegratorType.Path(yk.PathParams(max_depth=8))
-ctxs = [yk.Context(0), yk.Context(0)]
+ctxs = [yk.Context(0, **OPTS), yk.Context(0, **OPTS)]
 sc = yk.Scene(ctxs[0], sd)
 cam = yk.Camera(sd.camera, fs)
 its = [yk.IntegratorType.instantiate(c, integ) for c in ctxs]

@@ -1084,7 +1084,9 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
     HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64, st));
     KernelTimer kt;
     kt.ctx = ctx;
-    kt.on = stats != nullptr && ctx->time_kernels != 0;
+    // per-kernel HIP-event timings: two event records per launch and one elapsed-time query per
+    // kernel — not for jobs so small (a tile, a few tiles) that this bookkeeping is the cost
+    kt.on = stats != nullptr && ctx->time_kernels != 0 && (total_work >= (1u << 20) || ctx->time_kernels > 1);
     struct EventPair {  // destroyed on every exit path
         hipEvent_t a = nullptr, b = nullptr;
         ~EventPair() {
