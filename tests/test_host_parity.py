@@ -156,3 +156,21 @@ def test_scene_generators_are_deterministic():
     c = scenes.by_name("cfg2")
     assert c.n_triangles == 69312
     assert abs(np.abs(c.points).max() - 0.5) < 1e-6  # fitted to the unit cube like scene/ply.rs:99-108
+
+
+@pytest.mark.parametrize("method,max_shapes", [(abi.SPLIT_SAH, 1), (abi.SPLIT_SAH, 4), (abi.SPLIT_MIDDLE, 1), (abi.SPLIT_EQUAL_COUNTS, 2)])
+def test_parallel_bvh_build_is_the_sequential_one(yk, oracle, method, max_shapes, monkeypatch):
+    """Inputs of 2^16 shapes or more are built by worker threads (subtrees cut off the top, spliced
+    back in depth-first order): the tree equals the single-threaded build and the oracle's
+    sequential builder, node for node, for every thread count."""
+    sd = scenes.city((12, 10), 3, 1, "mixed")  # 153,610 triangles
+    sd.split_method, sd.max_shapes_in_node = method, max_shapes
+    assert sd.n_triangles >= 1 << 16
+    n_ref, o_ref = oracle.OracleScene(sd).export_bvh()
+    for threads in ("1", "2", "5", "16"):
+        monkeypatch.setenv("YK_BVH_THREADS", threads)
+        hs = yk.Scene(None, sd)
+        n, o = hs.export_bvh()
+        assert n.tobytes() == n_ref.tobytes(), threads
+        assert np.array_equal(o, o_ref), threads
+        assert hs.info().n_nodes == len(n_ref)

@@ -11,7 +11,12 @@
 
 #include <sys/stat.h>
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <thread>
 
 #include <cmath>
 #include <cstring>
@@ -329,20 +334,64 @@ void select_nth(Prim* a, size_t lo, size_t hi, size_t k, int axis) {
     }
 }
 
+// fn(chunk_index, lo, hi) on `threads` contiguous chunks of [start, end), chunk 0 on the caller
+template <class Fn> void for_chunks(size_t start, size_t end, unsigned threads, Fn fn) {
+    const size_t n = end - start, per = (n + threads - 1) / threads;
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) {
+        const size_t lo = start + std::min(n, per * t), hi = start + std::min(n, per * (t + 1));
+        pool.emplace_back([=] { fn(t, lo, hi); });
+    }
+    fn(0u, start, start + std::min(n, per));
+    for (std::thread& th : pool) th.join();
+}
+const size_t kParallelRange = (size_t)1 << 18;  // ranges at least this long are reduced by several threads
+const unsigned kMaxThreads = 32;
+
+// A subtree cut off the top of the tree and built by a worker thread into its own arena.
+struct alignas(256) SubtreeTask {  // own cache lines: every leaf a worker emits moves its arena's vector ends
+    size_t start, end;
+    uint32_t depth;
+    HostBvh arena;
+};
+const uint8_t kTaskMarker = 2;  // yk_bvh_node::is_leaf of a placeholder in the top arena (a = task index)
+
 struct Builder {
-    std::vector<Prim> prims;
+    Prim* prims;
     uint32_t max_shapes;
     uint32_t method;
     HostBvh* out;
+    // top phase of the parallel build: ranges of at most `grain` shapes become tasks
+    std::vector<SubtreeTask>* tasks = nullptr;
+    size_t grain = 0;
+    unsigned par_threads = 1;  // > 1 in the top phase: the three reductions over a long range (bounds, centroid
+                               // bounds, SAH buckets) are split over threads; min / max / counts merge exactly
+
+    Box range_bounds(size_t start, size_t end, bool centroids) const {
+        auto one = [&](size_t lo, size_t hi) {
+            Box b = box_empty();
+            if (centroids)
+                for (size_t i = lo; i < hi; ++i) box_add_point(b, prims[i].c);
+            else
+                for (size_t i = lo; i < hi; ++i) box_add_box(b, prims[i].bmin, prims[i].bmax);
+            return b;
+        };
+        if (par_threads <= 1 || end - start < kParallelRange) return one(start, end);
+        Box part[kMaxThreads];
+        for_chunks(start, end, par_threads, [&](unsigned t, size_t lo, size_t hi) { part[t] = one(lo, hi); });
+        Box b = part[0];
+        for (unsigned t = 1; t < par_threads; ++t) box_add_box(b, part[t].lo, part[t].hi);
+        return b;
+    }
 
     size_t split_equal_counts(size_t start, size_t end, int axis) {
         size_t mid = (start + end) / 2;
-        select_nth(prims.data(), start, end, mid, axis);
+        select_nth(prims, start, end, mid, axis);
         return mid;
     }
     size_t split_middle(const Box& cb, size_t start, size_t end, int axis) {
         const float mid_value = (cb.lo[axis] + cb.hi[axis]) / 2.0f;
-        return swap_partition(prims.data(), start, end, [&](const Prim& p) { return p.c[axis] < mid_value; }) + start;
+        return swap_partition(prims, start, end, [&](const Prim& p) { return p.c[axis] < mid_value; }) + start;
     }
     size_t split_sah(const Box& bounds, const Box& cb, size_t start, size_t end, int axis) {
         const size_t n = end - start;
@@ -353,10 +402,24 @@ struct Builder {
             counts[b] = 0;
             boxes[b] = box_empty();
         }
-        for (size_t i = start; i < end; ++i) {
-            int b = sah_bucket(cb, prims[i], axis);
-            counts[b] += 1;
-            box_add_box(boxes[b], prims[i].bmin, prims[i].bmax);
+        auto fill = [&](size_t lo, size_t hi, size_t* cnt, Box* bx) {
+            for (size_t i = lo; i < hi; ++i) {
+                int b = sah_bucket(cb, prims[i], axis);
+                cnt[b] += 1;
+                box_add_box(bx[b], prims[i].bmin, prims[i].bmax);
+            }
+        };
+        if (par_threads <= 1 || n < kParallelRange) {
+            fill(start, end, counts, boxes);
+        } else {
+            std::vector<size_t> pc((size_t)par_threads * kBuckets, 0);
+            std::vector<Box> pb((size_t)par_threads * kBuckets, box_empty());
+            for_chunks(start, end, par_threads, [&](unsigned t, size_t lo, size_t hi) { fill(lo, hi, &pc[(size_t)t * kBuckets], &pb[(size_t)t * kBuckets]); });
+            for (unsigned t = 0; t < par_threads; ++t)
+                for (int b = 0; b < kBuckets; ++b) {
+                    counts[b] += pc[(size_t)t * kBuckets + b];
+                    box_add_box(boxes[b], pb[(size_t)t * kBuckets + b].lo, pb[(size_t)t * kBuckets + b].hi);
+                }
         }
         float best_cost = 0.0f;
         int best = 0;
@@ -379,7 +442,7 @@ struct Builder {
             }
         }
         if (best_cost < (float)n)
-            return swap_partition(prims.data(), start, end, [&](const Prim& p) { return sah_bucket(cb, p, axis) <= best; }) + start;
+            return swap_partition(prims, start, end, [&](const Prim& p) { return sah_bucket(cb, p, axis) <= best; }) + start;
         return kNoSplit;
     }
 
@@ -401,13 +464,24 @@ struct Builder {
 
     // returns the node index (== depth-first position, as flatten_tree assigns it)
     uint32_t build(size_t start, size_t end, uint32_t depth) {
+        if (tasks && depth > 1 && end - start <= grain) {  // cut here: a worker builds this subtree
+            SubtreeTask t;
+            t.start = start;
+            t.end = end;
+            t.depth = depth;
+            tasks->push_back(std::move(t));
+            yk_bvh_node ph;
+            std::memset(&ph, 0, sizeof(ph));
+            ph.a = (uint32_t)tasks->size() - 1;
+            ph.is_leaf = kTaskMarker;
+            out->nodes.push_back(ph);
+            return (uint32_t)out->nodes.size() - 1;
+        }
         if (depth > out->depth) out->depth = depth;
-        Box bounds = box_empty();
-        for (size_t i = start; i < end; ++i) box_add_box(bounds, prims[i].bmin, prims[i].bmax);
+        const Box bounds = range_bounds(start, end, false);
         const size_t n = end - start;
         if (n <= max_shapes) return emit_leaf(bounds, start, end);
-        Box cb = box_empty();
-        for (size_t i = start; i < end; ++i) box_add_point(cb, prims[i].c);
+        const Box cb = range_bounds(start, end, true);
         const int axis = box_max_extent(cb);
         if (cb.hi[axis] == cb.lo[axis]) return emit_leaf(bounds, start, end);
         size_t mid;
@@ -446,6 +520,13 @@ struct Builder {
 
 }  // namespace
 
+// The build is the reference's recursion (bvh.rs:305-420), node for node.  For large inputs the
+// recursion is cut where a range holds at most n / (8 * threads) shapes: the top of the tree is
+// built on the calling thread exactly as before (same partitions in the same order on the same
+// data), the cut-off ranges — disjoint slices of the primitive array, which nothing else touches
+// — are built by worker threads into arenas of their own, and the arenas are spliced back in
+// depth-first order with their node and shape indices rebased.  The result is the sequential
+// build's, bit for bit (tests/test_bvh.py compares it with the oracle's sequential builder).
 void build_bvh(const std::vector<ShapeBounds>& bounds, uint32_t max_shapes_in_node, uint32_t split_method, HostBvh& out) {
     out.nodes.clear();
     out.shape_order.clear();
@@ -453,13 +534,9 @@ void build_bvh(const std::vector<ShapeBounds>& bounds, uint32_t max_shapes_in_no
     out.depth = 0;
     out.split_failed = false;
     if (bounds.empty()) return;
-    Builder b;
-    b.max_shapes = max_shapes_in_node;
-    b.method = split_method;
-    b.out = &out;
-    b.prims.resize(bounds.size());
+    std::vector<Prim> prims(bounds.size());
     for (size_t i = 0; i < bounds.size(); ++i) {
-        Prim& p = b.prims[i];
+        Prim& p = prims[i];
         p.shape = (uint32_t)i;
         for (int k = 0; k < 3; ++k) {
             p.bmin[k] = bounds[i].bmin[k];
@@ -467,9 +544,101 @@ void build_bvh(const std::vector<ShapeBounds>& bounds, uint32_t max_shapes_in_no
             p.c[k] = p.bmin[k] + ((p.bmax[k] - p.bmin[k]) / 0.5f);
         }
     }
+    Builder b;
+    b.prims = prims.data();
+    b.max_shapes = max_shapes_in_node;
+    b.method = split_method;
+    unsigned n_threads = std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("YK_BVH_THREADS")) n_threads = (unsigned)std::max(1, std::atoi(e));
+    n_threads = std::min(n_threads, kMaxThreads);
+    if (n_threads <= 1 || bounds.size() < (1u << 16)) {  // small inputs: the plain recursion
+        b.out = &out;
+        out.nodes.reserve(bounds.size() * 2);
+        out.shape_order.reserve(bounds.size());
+        b.build(0, bounds.size(), 1);
+        return;
+    }
+    // ---- top of the tree, with placeholders where subtrees are cut off
+    HostBvh top;
+    std::vector<SubtreeTask> tasks;
+    b.out = &top;
+    b.tasks = &tasks;
+    b.grain = std::max<size_t>(bounds.size() / (8u * n_threads), std::max<size_t>(4096, max_shapes_in_node));
+    b.par_threads = n_threads;
+    const bool tm = std::getenv("YK_BVH_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    b.build(0, bounds.size(), 1);
+    const double t1 = now();
+    // ---- the subtrees, largest first
+    std::vector<size_t> order(tasks.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return tasks[x].end - tasks[x].start > tasks[y].end - tasks[y].start; });
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= order.size()) return;
+            SubtreeTask& t = tasks[order[k]];
+            Builder w;
+            w.prims = prims.data();
+            w.max_shapes = max_shapes_in_node;
+            w.method = split_method;
+            w.out = &t.arena;
+            t.arena.nodes.reserve((t.end - t.start) * 2);
+            t.arena.shape_order.reserve(t.end - t.start);
+            w.build(t.start, t.end, t.depth);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned i = 1; i < n_threads && i < tasks.size(); ++i) pool.emplace_back(work);
+    work();
+    for (std::thread& th : pool) th.join();
+    const double t2 = now();
+    // ---- splice: the top arena is in depth-first order already, so one pass in index order lays
+    // out the final array; interior nodes of the top get their second child and bounds afterwards
+    out.depth = top.depth;
+    out.max_leaf_shapes = top.max_leaf_shapes;
+    out.split_failed = top.split_failed;
     out.nodes.reserve(bounds.size() * 2);
     out.shape_order.reserve(bounds.size());
-    b.build(0, bounds.size(), 1);
+    std::vector<uint32_t> final_index(top.nodes.size());
+    for (size_t i = 0; i < top.nodes.size(); ++i) {
+        const yk_bvh_node& tn = top.nodes[i];
+        final_index[i] = (uint32_t)out.nodes.size();
+        if (tn.is_leaf == kTaskMarker) {
+            const HostBvh& a = tasks[tn.a].arena;
+            const uint32_t node_base = (uint32_t)out.nodes.size(), shape_base = (uint32_t)out.shape_order.size();
+            for (yk_bvh_node n : a.nodes) {
+                n.a += n.is_leaf ? shape_base : node_base;
+                out.nodes.push_back(n);
+            }
+            out.shape_order.insert(out.shape_order.end(), a.shape_order.begin(), a.shape_order.end());
+            out.depth = std::max(out.depth, a.depth);
+            out.max_leaf_shapes = std::max(out.max_leaf_shapes, a.max_leaf_shapes);
+            out.split_failed = out.split_failed || a.split_failed;
+        } else if (tn.is_leaf) {
+            yk_bvh_node n = tn;
+            n.a = (uint32_t)out.shape_order.size();
+            out.shape_order.insert(out.shape_order.end(), top.shape_order.begin() + tn.a, top.shape_order.begin() + tn.a + tn.count);
+            out.nodes.push_back(n);
+        } else {
+            out.nodes.push_back(tn);
+        }
+    }
+    for (size_t i = top.nodes.size(); i-- > 0;) {
+        const yk_bvh_node& tn = top.nodes[i];
+        if (tn.is_leaf) continue;
+        yk_bvh_node& me = out.nodes[final_index[i]];
+        const uint32_t c0 = final_index[i + 1], c1 = final_index[tn.a];
+        const yk_bvh_node &n0 = out.nodes[c0], &n1 = out.nodes[c1];
+        for (int k = 0; k < 3; ++k) {  // BVHBuildNode::interior: child0.bounds.union_b(child1.bounds)
+            me.bmin[k] = rmin(n0.bmin[k], n1.bmin[k]);
+            me.bmax[k] = rmax(n0.bmax[k], n1.bmax[k]);
+        }
+        me.a = c1;
+    }
+    if (tm) std::fprintf(stderr, "[bvh] top %.3f s (%zu tasks, grain %zu), subtrees %.3f s on %u threads, splice %.3f s\n", t1 - t0, tasks.size(), b.grain, t2 - t1, n_threads, now() - t2);
 }
 
 }  // namespace yk
