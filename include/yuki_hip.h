@@ -224,8 +224,9 @@ void* yk_context_stream(const yk_context* ctx);
  * "packet_bounces" / "packet_shadow_bounces" (leading bounces traced by the wave-packet
  * kernels), "overlap_shadow" (0|1), "shade_reorder" (0|1: paths of a shade block dealt to
  * lanes by material kind), "top_nodes" (tree-top nodes the traversal kernels keep
- * in LDS, 0..255) and "wide_bvh" (0|1: traverse the 4-wide collapse of the BVH) — the last
- * two apply to scenes created afterwards. */
+ * in LDS, 0..255) and "wide_bvh" (0: binary nodes only | 1: traverse the 4-wide collapse of the
+ * BVH | 2, default: keep both, jobs of up to 6 M paths use the 4-wide one) — the last two apply
+ * to scenes created afterwards. */
 yk_status yk_context_set_option(yk_context* ctx, const char* key, int64_t value);
 
 /* ---- host-side restatements (no GPU needed) -------------------------------- */

@@ -211,7 +211,7 @@ def test_error_behaviour(ctx, yk):
     assert e.value.status == 7
 
 
-@pytest.mark.parametrize("option,value", [("wide_bvh", 1), ("top_nodes", 0), ("top_nodes", 7), ("packet_bounces", 0), ("packet_bounces", 8), ("packet_shadow_bounces", 8), ("overlap_shadow", 0)])
+@pytest.mark.parametrize("option,value", [("wide_bvh", 0), ("wide_bvh", 1), ("top_nodes", 0), ("top_nodes", 7), ("packet_bounces", 0), ("packet_bounces", 8), ("packet_shadow_bounces", 8), ("overlap_shadow", 0)])
 def test_traversal_layout_options_do_not_change_the_image(yk, oracle, option, value):
     """The traversal variants — 4-wide collapse of the BVH (DevNode4), number of top-of-tree
     nodes kept in LDS, wave-packet kernels for none / all bounces (closest and shadow rays),

@@ -57,7 +57,7 @@ struct yk_context {
     int64_t packet_shadow_bounces = 1;  // same for the shadow rays towards point / spot / distant lights (their own queue)
     int64_t shade_reorder = 1;   // deal the paths of a shade block to its lanes sorted by material kind (bounces > 0)
     int64_t overlap_shadow = 1;  // run {trace_any, accumulate}(b) on a side stream beside trace_closest(b+1)
-    int64_t wide_bvh = 0;   // traverse the 4-wide collapse of the BVH (scenes created afterwards)
+    int64_t wide_bvh = 2;   // scenes created afterwards: 0 binary nodes only, 1 traverse the 4-wide collapse, 2 keep both and pick per job
     int64_t top_nodes = YK_TOP_MAX; // interior nodes (capped by what the kernels were built for) of the first tree levels the traversal kernels keep in LDS
     int64_t sample_buf_cap = (int64_t)64 << 30;
     int64_t time_kernels = 1;
@@ -81,17 +81,27 @@ struct yk_context {
 };
 
 typedef yk_context::WorkSet WorkSet;
+static const uint32_t YK_WIDE_MAX_PATHS = 6u << 20;  // jobs up to this many paths traverse the 4-wide nodes (wide_bvh = 2)
 
 struct yk_scene {
     int device = -1;  // a scene belongs to the device, not to the context that made it: any context there renders it, and it may outlive them
     HostBvh bvh;
     uint32_t n_triangles = 0, n_spheres = 0, n_lights = 0, n_delta_lights = 0;
+    bool wide_auto = false;  // both node layouts on the device: the 4-wide one is used for jobs below YK_WIDE_MAX_PATHS
     yk_scene_info info;
     // device
     DevBuf nodes, nodes4, top_nodes, tris, prim_shade, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights, spheres, texels, tex_info;
     DevScene dev;
     bool on_device = false;
 };
+
+// The device scene a job of `n` rays traverses: with both node layouts present the 4-wide one
+// serves small jobs only (see run_bounces).
+static DevScene dev_scene_for(const yk_scene* scene, uint64_t n) {
+    DevScene ds = scene->dev;
+    if (scene->wide_auto && n > YK_WIDE_MAX_PATHS) ds.nodes4 = nullptr;
+    return ds;
+}
 
 // A tile list prepared once and reused every frame (the GPU worker renders the same tiles
 // over and over): host copy + the device pixel table, so that rendering and the film update
@@ -177,7 +187,7 @@ yk_status yk_context_create(int device, yk_context** out) {
         return YK_ERR_DEVICE;
     }
     ctx->ws[0].stream = ctx->stream;
-    if (const char* w = std::getenv("YK_WIDE_BVH")) ctx->wide_bvh = std::atoi(w) != 0;  // experiments; same as set_option("wide_bvh")
+    if (const char* w = std::getenv("YK_WIDE_BVH")) ctx->wide_bvh = std::min(std::max(std::atoi(w), 0), 2);  // experiments; same as set_option("wide_bvh")
     if (const char* w = std::getenv("YK_PACKET_BOUNCES")) ctx->packet_bounces = std::max(std::atoi(w), 0);
     if (const char* w = std::getenv("YK_PACKET_SHADOW_BOUNCES")) ctx->packet_shadow_bounces = std::max(std::atoi(w), 0);
     if (const char* w = std::getenv("YK_TOP_NODES")) ctx->top_nodes = std::min(std::max(std::atoi(w), 0), YK_TOP_MAX);
@@ -249,7 +259,8 @@ yk_status yk_context_set_option(yk_context* ctx, const char* key, int64_t value)
         if (value < 0 || value > YK_TOP_MAX) return YK_ERR_INVALID_ARGUMENT;
         ctx->top_nodes = value;
     } else if (k == "wide_bvh") {
-        ctx->wide_bvh = value != 0;
+        if (value < 0 || value > 2) return YK_ERR_INVALID_ARGUMENT;
+        ctx->wide_bvh = value;
     } else if (k == "time_kernels") {
         ctx->time_kernels = value;
     } else {
@@ -734,6 +745,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         DevScene& ds = s->dev;
         ds.nodes = s->nodes.as<DevNode>();
         ds.nodes4 = wide ? s->nodes4.as<DevNode4>() : nullptr;
+        s->wide_auto = wide && ctx->wide_bvh == 2;
         ds.top_nodes = s->top_nodes.as<DevNode>();
         ds.n_top = (uint32_t)top.size();
         ds.tris = s->tris.as<float4>();
@@ -900,7 +912,12 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
                         const uint32_t* sample_index_tab, float4* sample_buf, KernelTimer& kt, unsigned long long* counters, bool coherent,
                         uint32_t n_paths, uint32_t* n_shadow_launches = nullptr) {
     unsigned* ctrl = ws.ctrl.as<unsigned>();
-    const DevScene& ds = scene->dev;
+    // Two node layouts: the binary 64-byte nodes win when the machine is full (one 4-wide node
+    // costs the loads of two binary ones, and throughput is bound by per-lane loads);
+    // the 4-wide collapse halves the dependent steps of a ray, which is what a job too small to
+    // fill the machine waits for (a 16x16 tile: 1.83 -> 1.38 ms, a 1080p pass: 7.7 -> 7.0 ms,
+    // equal at 8 M paths, 9 % slower for the 132 M-path frame).
+    const DevScene ds = dev_scene_for(scene, n_paths);
     // Queue lengths are only known on the device, but none exceeds the batch's path count
     // (x lights for shadow rays).  A small job — one 16x16 tile of the reference's per-tile
     // calls is 16 K paths — gets grids of that size instead of machine-filling ones: every wave
@@ -1170,7 +1187,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
                 PathBuffers pc = path_buffers(ws, 0);
                 const bool want_stats = prm.integrator == YK_INTEGRATOR_BVH_INTERSECTIONS;
                 int e = kt.begin(bs);
-                launch_trace_closest(bs, trace_grid(ctx), scene->dev, pc.rayO, pc.rayD, nullptr, ctrl + YK_CTRL_BOUNCE(0), ctrl + YK_CTRL_BOUNCE(0) + YK_CTRL_HEAD, ws.hit.as<int>(), nullptr,
+                launch_trace_closest(bs, trace_grid(ctx), dev_scene_for(scene, n), pc.rayO, pc.rayD, nullptr, ctrl + YK_CTRL_BOUNCE(0), ctrl + YK_CTRL_BOUNCE(0) + YK_CTRL_HEAD, ws.hit.as<int>(), nullptr,
                                      want_stats ? ctx->stats4.as<uint4>() : nullptr, ws.spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), ctrl,
                                      counters);
                 kt.end(e, 0, bs);
@@ -1551,7 +1568,7 @@ yk_status yk_trace_closest(yk_context* ctx, const yk_scene* scene, size_t n, con
     unsigned nn = (unsigned)n;
     HIP_TRY(ctx, hipMemcpyAsync(ctrl, &nn, 4, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    launch_trace_closest(st, trace_grid(ctx), scene->dev, pb.rayO, pb.rayD, t_max ? ctx->scratch[6].as<float>() : nullptr, ctrl, ctrl + YK_CTRL_HEADS,
+    launch_trace_closest(st, trace_grid(ctx), dev_scene_for(scene, n), pb.rayO, pb.rayD, t_max ? ctx->scratch[6].as<float>() : nullptr, ctrl, ctrl + YK_CTRL_HEADS,
                          ctx->ws[0].hit.as<int>(), ctx->hit4.as<float4>(), want_stats ? ctx->stats4.as<uint4>() : nullptr, ctx->ws[0].spill.as<uint2>(),
                          trace_grid(ctx) * trace_block_size(), ctrl, nullptr);
     HIP_TRY(ctx, hipGetLastError());
@@ -1611,7 +1628,7 @@ yk_status yk_trace_any(yk_context* ctx, const yk_scene* scene, size_t n, const f
     unsigned nn = (unsigned)n;
     HIP_TRY(ctx, hipMemcpyAsync(ctrl, &nn, 4, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    launch_trace_any(st, trace_grid(ctx), scene->dev, ctx->ws[0].shO.as<float4>(), ctx->ws[0].shD.as<float4>(), nullptr, ctrl, ctrl + YK_CTRL_HEADS,
+    launch_trace_any(st, trace_grid(ctx), dev_scene_for(scene, n), ctx->ws[0].shO.as<float4>(), ctx->ws[0].shD.as<float4>(), nullptr, ctrl, ctrl + YK_CTRL_HEADS,
                      ctx->ws[0].vis.as<unsigned char>(), ctx->ws[0].spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), ctrl, nullptr);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(out_hit, ctx->ws[0].vis.p, n, hipMemcpyDeviceToHost, st));
