@@ -84,6 +84,15 @@ YK_HD bool slab(V3 lo, V3 hi, V3 o, V3 inv, float t_max, float& tmin) {
     return tmin <= tmax;
 }
 
+// A box whose test is DEFERRED (the far child: the reference tests it when it pops it, with the
+// t_max of that moment) is screened with a relaxed bound when its parent is visited and checked
+// exactly (entry distance <= t_max) when popped.  "t_max only shrinks" does not hold in the
+// reference: the watertight triangle test accepts t_scaled <= t_max * det and returns
+// t = t_scaled / det (triangle.rs:126-139, no conservative t-error test), so a tie hit among
+// coplanar triangles can RAISE t_max by a few ulps, and a box culled at visit time by the
+// exact bound would pass at pop time.  2^-10 relative covers thousands of such raises.
+YK_HD float deferred_t_max(float t_max) { return t_max * 1.0009765625f; }
+
 // SurfaceInteraction after Triangle::intersect, triangle.rs:141-226 +
 // interaction.rs:95-132 — the fields the integrator reads.
 struct Surface {

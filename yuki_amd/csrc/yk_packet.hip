@@ -17,7 +17,7 @@
 //   * the far child is pushed untested by the reference and tested when popped with the
 //     then-current t_max: the packet stack keeps (parent, which child, lanes that visited the
 //     parent and hit the child's box at push time) and re-tests the child's box per lane at
-//     pop time — lanes that missed at push time would miss again since t_max only shrinks;
+//     pop time — lanes are remembered by a relaxed bound at push time (t_max can rise by ulps on tie hits, yk_geom.h);
 //   * leaf primitives are tested in order and a later hit with t == t_max replaces the
 //     earlier one (triangle.rs:126-127), per lane as in the scalar code.
 // any_intersect (bvh.rs:235-302) is order-independent: one group, lanes retire when occluded.
@@ -139,15 +139,20 @@ __device__ __forceinline__ void pkt_closest_group(const DevScene& sc, PktStack& 
             const PktNode nb = pkt_load_node(sc.nodes, cur);
             const bool mine = in_mask(cmask);
             float t0, t1;
-            const bool h0 = mine && slab(nb.lo0, nb.hi0, r.o, r.inv, r.t_max, t0);
-            const bool h1 = mine && slab(nb.lo1, nb.hi1, r.o, r.inv, r.t_max, t1);
+            // exact bound for a child entered now; a deferred (far) child is re-tested exactly when popped, so the
+            // lanes remembered for it are screened with the relaxed bound (yk_geom.h: t_max can rise by ulps)
+            const float t_def = deferred_t_max(r.t_max);
+            const bool r0 = mine && slab(nb.lo0, nb.hi0, r.o, r.inv, t_def, t0);
+            const bool r1 = mine && slab(nb.lo1, nb.hi1, r.o, r.inv, t_def, t1);
+            const bool h0 = r0 && t0 <= r.t_max, h1 = r1 && t1 <= r.t_max;
             const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
             const bool swap = (sg >> nb.axis) & 1u;
             const unsigned near_ref = swap ? nb.ref1 : nb.ref0, far_ref = swap ? nb.ref0 : nb.ref1;
             const unsigned long long m_near = swap ? m1 : m0, m_far = swap ? m0 : m1;
+            const unsigned long long m_far_def = __ballot(swap ? r0 : r1);
             if (m_near) {
-                if (m_far) {
-                    stk.push(sp, cur, swap ? 0u : 1u, m_far);  // which = index of the far child in the parent
+                if (m_far_def) {
+                    stk.push(sp, cur, swap ? 0u : 1u, m_far_def);  // which = index of the far child in the parent
                     ++sp;
                 }
                 cur = near_ref;

@@ -180,10 +180,11 @@ __device__ __forceinline__ Step4 node4_step(const DevNode4* nodes, unsigned idx,
 
 // Closest hit with the reference's visiting order (near child first by the sign
 // of the direction along the split axis, far child deferred, leaves in shape
-// order, a later hit with t == t_max replaces the earlier one).  Box tests of a
-// deferred child are evaluated when its parent is visited and completed at pop
-// time by `tmin <= t_max`, which is exactly the reference's test at pop time
-// because t_max only shrinks (DESIGN.md §traversal equivalence).
+// order, a later hit with t == t_max replaces the earlier one).  The box of a
+// deferred child is evaluated when its parent is visited — against a slightly
+// relaxed bound, because a tie hit can raise t_max by a few ulps (deferred_t_max,
+// yk_geom.h) — and completed at pop time by the exact `tmin <= t_max`, which is the
+// reference's test at pop time (DESIGN.md §traversal equivalence).
 template <int BLOCK, int LDS_DEPTH, bool STATS>
 __device__ __forceinline__ void traverse_closest(const DevScene& sc, V3 o, V3 d, float t_max_in, TravStack<BLOCK, LDS_DEPTH>& stk, int& out_tri,
                                                  TriHit& out_hit, unsigned& node_tests, unsigned& node_hits, unsigned& shape_tests,
@@ -203,11 +204,13 @@ __device__ __forceinline__ void traverse_closest(const DevScene& sc, V3 o, V3 d,
         if (!(cur & YK_LEAF_BIT)) {
             NodeBoxes nb = load_node(sc.nodes, cur);
             float t0, t1;
-            bool h0 = slab(nb.lo0, nb.hi0, o, inv, t_max, t0);
-            bool h1 = slab(nb.lo1, nb.hi1, o, inv, t_max, t1);
+            const float t_def = deferred_t_max(t_max);
+            bool h0 = slab(nb.lo0, nb.hi0, o, inv, t_def, t0);
+            bool h1 = slab(nb.lo1, nb.hi1, o, inv, t_def, t1);
             bool swap = neg[nb.axis];
             unsigned near_ref = swap ? nb.ref1 : nb.ref0, far_ref = swap ? nb.ref0 : nb.ref1;
-            bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
+            // the near child is entered now: exact bound; the far child is deferred: relaxed now, exact at pop
+            bool near_hit = (swap ? h1 : h0) && (swap ? t1 : t0) <= t_max, far_hit = swap ? h0 : h1;
             float far_t = swap ? t0 : t1;
             if (STATS) {
                 node_tests += 1;  // the near child is tested right away; the far one is counted when popped
@@ -441,8 +444,18 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(Dev
         if (__any(on_node) && n_leaf < (unsigned)LEAF_MIN) {
             if (WIDE) {
                 if (on_node) {
-                    Step4 st = node4_step(sc.nodes4, cur, r.o, r.inv, r.t_max, r.negmask);
-                    // push the later-visited hits (last first); the first one is entered right away
+                    Step4 st = node4_step(sc.nodes4, cur, r.o, r.inv, deferred_t_max(r.t_max), r.negmask);
+                    // The first slot (in visiting order) that passes the exact bound is entered right away; slots
+                    // before it fail now as they would in the reference (t_max cannot change before they are
+                    // tested); the later ones are deferred: relaxed here, exact when popped (yk_geom.h).
+                    bool entered = false;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool exact = st.ref[k] != YK_REF_NONE && st.t[k] <= r.t_max;
+                        if (!entered && !exact) st.ref[k] = YK_REF_NONE;
+                        entered = entered || exact;
+                    }
+                    // push the later-visited hits (last first)
                     unsigned next = YK_REF_NONE;
                     float next_t = 0.0f;
 #pragma unroll
@@ -473,11 +486,12 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(Dev
                 NodeBoxes nb = (cur & YK_TOP_BIT) ? load_node_lds(lds_top, cur & ~YK_TOP_BIT) : load_node(sc.nodes, cur);
                 YK_EXPERIMENT_NODE(sc.nodes + cur, nb);
                 float t0, t1;
-                bool h0 = slab(nb.lo0, nb.hi0, r.o, r.inv, r.t_max, t0);
-                bool h1 = slab(nb.lo1, nb.hi1, r.o, r.inv, r.t_max, t1);
+                const float t_def = deferred_t_max(r.t_max);  // yk_geom.h: a deferred box is screened with a relaxed bound
+                bool h0 = slab(nb.lo0, nb.hi0, r.o, r.inv, t_def, t0);
+                bool h1 = slab(nb.lo1, nb.hi1, r.o, r.inv, t_def, t1);
                 bool swap = (r.negmask >> nb.axis) & 1u;
                 unsigned near_ref = swap ? nb.ref1 : nb.ref0, far_ref = swap ? nb.ref0 : nb.ref1;
-                bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
+                bool near_hit = (swap ? h1 : h0) && (swap ? t1 : t0) <= r.t_max, far_hit = swap ? h0 : h1;
                 float far_t = swap ? t0 : t1;
                 if (near_hit) {
                     if (far_hit) {
@@ -490,8 +504,8 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(Dev
                         }
                     }
                     cur = near_ref;
-                } else if (far_hit) {
-                    cur = far_ref;  // no intervening leaf can shrink t_max: the test result is final
+                } else if (far_hit && far_t <= r.t_max) {
+                    cur = far_ref;  // entered now (no leaf in between): the exact bound decides
                 } else if (!pop_closest(stk, sp, r.t_max, cur)) {
                     hit_tri[ray_i] = best;
                     if (API && hit_out) hit_out[ray_i] = make_float4(best_hit.t, best_hit.b0, best_hit.b1, best_hit.b2);
