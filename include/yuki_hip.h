@@ -276,8 +276,9 @@ yk_status yk_render_tiles_device(yk_context* ctx, const yk_scene* scene, const y
                                  void* user);
 /* Integrator::render(accumulating = true) (integrators/mod.rs:146-161; the tile queue of
  * render_manager.rs:135-143): ONE sample per pixel whose global sample index is the tile's
- * FilmTile.sample (tile_samples[t], u16 like film.rs:52); the raw radiance is stored (divided
- * by 1).  Fold the result into the film with yk_film_accumulate_tiles[_device]; the displayed
+ * FilmTile.sample (tile_samples[t], u16 like film.rs:52, which must be below the sampler's
+ * samples per pixel as in render_manager.rs:135-143 — YK_ERR_INVALID_ARGUMENT otherwise); the
+ * raw radiance is stored (divided by 1).  Fold the result into the film with yk_film_accumulate_tiles[_device]; the displayed
  * image is film / samples (tonemap.rs:240-241). */
 yk_status yk_render_tiles_accumulating(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
                                        const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,

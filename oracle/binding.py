@@ -187,6 +187,7 @@ class OracleScene:
         tiles = np.ascontiguousarray(tiles, dtype=abi.TILE_DTYPE)
         ts = np.ascontiguousarray(tile_samples, dtype=np.uint16)
         assert len(ts) == len(tiles)
+        assert int(ts.max()) < int(sampler.nx) * max(1, int(sampler.ny) if sampler.kind == 1 else 1), "sample index outside the sampler's domain (the permutation walk need not terminate)"
         npx = int(((tiles["x1"].astype(np.int64) - tiles["x0"]) * (tiles["y1"].astype(np.int64) - tiles["y0"])).sum())
         out = np.zeros((npx, 3), dtype=np.float32)
         rays = C.c_uint64(0)

@@ -288,3 +288,9 @@ def test_several_accumulating_passes_in_one_submission(ctx, yk, oracle, integ_na
     assert film_a.cpu().numpy().tobytes() == host.tobytes()
     with pytest.raises(yk.YukiError):
         it.render_tiles_accumulating(sc, cam, smp, tiles, first, n_passes=70000)
+    # the reference queues samples 0 .. spp-1 only (render_manager.rs:135-143); beyond that the stratified
+    # permutation walk need not terminate, so the library refuses instead of launching
+    with pytest.raises(yk.YukiError, match="beyond the sampler"):
+        it.render_tiles_accumulating(sc, cam, smp, tiles, first + 8, n_passes=2)
+    with pytest.raises(yk.YukiError, match="beyond the sampler"):
+        it.render_tiles_accumulating(sc, cam, smp, tiles, np.full(len(tiles), 9, dtype=np.uint16))

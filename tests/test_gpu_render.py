@@ -397,4 +397,4 @@ def test_random_scenes_match_the_oracle(ctx, yk, oracle, seed):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import parity_fuzz
 
-    assert parity_fuzz.check_seed(ctx, oracle, seed) == []
+    assert parity_fuzz.check_seed(None, oracle, seed) == []  # None: the context options cycle with the seed (both node layouts, ...)

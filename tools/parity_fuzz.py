@@ -38,6 +38,14 @@ def random_scene(seed):
             mats.append(dict(kind=abi.MAT_GLOSSY, a=tuple(r.uniform(0, 1, 3)), c=float(r.choice([0.0, 0.01, 0.3, 1.0])), remap=bool(r.integers(0, 2))))
         else:
             mats.append(dict(kind=abi.MAT_MATTE, a=(0.0, 0.0, 0.0), c=0.0))  # black: no lobes
+    textures = []
+    for m in mats:  # image textures on some matte materials (point-sampled, repeat, uv far outside [0, 1])
+        if m["kind"] == abi.MAT_MATTE and r.random() < 0.4:
+            th, tw = int(r.integers(1, 9)), int(r.integers(1, 9))
+            t = r.uniform(0, 1, (th, tw, 3)).astype(F)
+            t[r.random((th, tw)) < 0.2] = 0  # black texels: no lobe there (matte.rs:31)
+            m["tex"] = len(textures)
+            textures.append(t)
     lights = []
     for _ in range(int(r.integers(0, 4))):
         k = int(r.integers(0, 4))
@@ -78,6 +86,25 @@ def random_scene(seed):
         tal += [int(r.choice(rect_ids)) if (rect_ids and r.random() < 0.1) else -1 for _ in range(nt)]
         meshes.append((hn, hu, bool(r.integers(0, 2))))
         base += nv
+    if r.random() < 0.25:  # a larger mesh: deeper tree, multi-level LDS top, long traversal stacks
+        g = int(r.integers(8, 60))
+        gx, gy = np.meshgrid(np.arange(g + 1), np.arange(g + 1), indexing="xy")
+        p = np.stack([gx.ravel() / g * 3 - 1.5, r.normal(scale=float(r.choice([0.0, 0.02, 0.3])), size=(g + 1) ** 2), gy.ravel() / g * 3 - 1.5], axis=1).astype(F)
+        p = p[:, r.permutation(3)]
+        a = (gy[:-1, :-1] * (g + 1) + gx[:-1, :-1]).ravel()
+        ii = np.concatenate([np.stack([a, a + 1, a + g + 2], axis=1), np.stack([a, a + g + 2, a + g + 1], axis=1)]).astype(np.uint32)
+        nv, nt = len(p), len(ii)
+        pts.append(p)
+        nn = r.normal(size=(nv, 3)).astype(F)
+        nn /= np.maximum(np.linalg.norm(nn, axis=1, keepdims=True), 1e-3).astype(F)
+        normals.append(nn.astype(F))
+        uvs.append(r.uniform(-2, 2, (nv, 2)).astype(F))
+        idx.append(ii + np.uint32(base))
+        tmesh += [len(meshes)] * nt
+        tmat += list(r.integers(0, n_mat, nt))
+        tal += [-1] * nt
+        meshes.append((bool(r.integers(0, 2)), bool(r.integers(0, 2)), bool(r.integers(0, 2))))
+        base += nv
     spheres = []
     for _ in range(int(r.integers(0, 3))):
         o2w, w2o = _translation(r.uniform(-1, 1, 3).astype(F))
@@ -92,11 +119,25 @@ def random_scene(seed):
         meshes=meshes, materials=mats, lights=lights, spheres=spheres, background=tuple(r.choice([0.0, 0.1, 1.0], 3)),
         split_method=int(r.integers(0, 3)), max_shapes_in_node=int(r.choice([1, 1, 2, 4, 255])),
         camera=dict(position=cam_pos, target=(0.0, 0.0, 0.0), up=up, fov_axis=int(r.integers(0, 2)), fov_degrees=float(r.uniform(20, 100))),
-        name=f"fuzz-{seed}")
+        textures=textures, name=f"fuzz-{seed}")
+
+
+# context options cycled by seed: both node layouts, with and without the LDS tree top, packets on deeper bounces
+VARIANTS = [{}, {"wide_bvh": 0}, {"wide_bvh": 1}, {"wide_bvh": 0, "top_nodes": 0}, {"wide_bvh": 0, "packet_bounces": 3, "packet_shadow_bounces": 3},
+            {"wide_bvh": 0, "overlap_shadow": 0, "shade_reorder": 0}, {"wide_bvh": 0, "batch_paths": 1500, "streams": 2}]
+_variant_ctx = {}
+
+
+def variant_context(seed):
+    k = seed % len(VARIANTS)
+    if k not in _variant_ctx:
+        _variant_ctx[k] = yk.Context(0, **VARIANTS[k])
+    return _variant_ctx[k]
 
 
 def check_seed(ctx, oracle, seed, res=(48, 32)):
-    """-> list of (integrator name, mismatching values)"""
+    """-> list of (integrator name, mismatching values); ctx = None: a context with the seed's option variant"""
+    ctx = ctx or variant_context(seed)
     r = np.random.default_rng(seed ^ 0x5EED)
     sd = random_scene(seed)
     fs = yk.FilmSettings(res=res, tile_dim=16)
@@ -116,6 +157,18 @@ def check_seed(ctx, oracle, seed, res=(48, 32)):
         same = (gb == wb) | (np.isnan(got) & np.isnan(want))  # a NaN is a NaN (payload bits are not defined by the reference)
         if not same.all() or st.rays != rays:
             bad.append((name, int((~same).sum()), st.rays, rays))
+    # the accumulating film: passes s0 .. s0 + 2 in one submission against the oracle's single passes
+    spp = yk.samples_per_pixel(smp)
+    n_passes = min(3, spp)
+    first = r.integers(0, spp - n_passes + 1, len(tiles)).astype(np.uint16)  # sample + passes <= spp (render_manager.rs:135-143)
+    it = yk.IntegratorType.instantiate(ctx, integs["path"])
+    got, st = it.render_tiles_accumulating(sc, cam, smp, tiles, first, n_passes=n_passes)
+    got = got.reshape(n_passes, -1, 3)
+    for k in range(n_passes):
+        want, _ = osc.render_tiles_accumulating(cam.matrices, smp, integs["path"], tiles, first + k)
+        same = (got[k].view(np.uint32) == want.view(np.uint32)) | (np.isnan(got[k]) & np.isnan(want))
+        if not same.all():
+            bad.append((f"accumulating pass {k}", int((~same).sum()), 0, 0))
     sc.close()
     return bad
 
@@ -125,11 +178,13 @@ if __name__ == "__main__":
 
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-    ctx = yk.Context(0)
     failures = 0
+    verbose = len(sys.argv) > 3
     for seed in range(first, first + count):
+        if verbose:
+            print(f"seed {seed} (variant {VARIANTS[seed % len(VARIANTS)]}) ...", flush=True)
         try:
-            bad = check_seed(ctx, oracle, seed)
+            bad = check_seed(None, oracle, seed)
         except yk.YukiError as e:
             print(f"seed {seed}: rejected by the library: {e}", flush=True)
             continue

@@ -1058,6 +1058,13 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
     // samples rendered per pixel by this call: the accumulating film renders passes FilmTile.sample .. + n_passes - 1
     const uint32_t spp = accumulating ? n_passes : prm.sampler.spp;
     prm.spe = spp;
+    if (accumulating) {
+        // render_manager.rs:135-143 queues samples 0 .. spp-1 of a tile and nothing else; an index beyond that is
+        // outside the samplers' domain (the stratified permutation walks cycles of [0, spp) and need not terminate)
+        for (size_t t = 0; t < n_tiles; ++t)
+            if ((uint64_t)tile_samples[t] + n_passes > prm.sampler.spp)
+                return fail(ctx, YK_ERR_INVALID_ARGUMENT, "FilmTile.sample (+ passes) beyond the sampler's samples per pixel");
+    }
     // chunk so that sample ids fit u32 and the sample buffer stays under the cap
     uint64_t max_px_chunk = std::min<uint64_t>(0xFFFFFFF0ull / spp, (uint64_t)ctx->sample_buf_cap / (16ull * spp));
     if (max_px_chunk == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "sample_buf_cap too small for one pixel");
@@ -1495,6 +1502,8 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
     if (prm.integrator != YK_INTEGRATOR_PATH && prm.integrator != YK_INTEGRATOR_WHITTED)
         return fail(ctx, YK_ERR_UNSUPPORTED, "yk_li implements the Path and Whitted integrators");
     prm.spe = 1;  // one table entry (pixel, sample index) per ray
+    for (size_t i = 0; i < n; ++i)
+        if (sample_index[i] >= prm.sampler.spp) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "sample_index >= samples per pixel");
     if (prm.max_depth > YK_CTRL_MAX_DEPTH) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "max_depth too large");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
