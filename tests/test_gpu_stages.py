@@ -204,3 +204,19 @@ def test_bsdf_f_and_sample_f_bit_exact(ctx, yk, oracle, mi):
         L.orc_bsdf_sample(C.byref(m), p(ng, i), p(ns, i), p(dpdu, i), p(wo, i), p(u, i), p(want_s, i))
     assert np.array_equal(_bits(got_f), _bits(want_f))
     assert np.array_equal(_bits(got_s), _bits(want_s))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(3000, 3021)))
+def test_degenerate_rays_on_random_scenes(oracle, seed):
+    """tools/stage_fuzz.py: intersect / any_intersect on random scenes for rays with exact zero
+    direction components (NaN lanes in the slab test), origins on box faces, rays through vertices
+    and along edges, |d| from 1e-6 to 1e6, t_max at the exact hit distance and one ulp around it:
+    hit shape, t bits, the reference's three counters and the occlusion verdicts equal the oracle's."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stage_fuzz
+
+    assert stage_fuzz.check_seed(oracle, seed) == []
