@@ -47,7 +47,7 @@ def random_scene(seed):
             m["tex"] = len(textures)
             textures.append(t)
     lights = []
-    for _ in range(int(r.integers(0, 4))):
+    for _ in range(int(r.choice([0, 1, 2, 3, 3, 4, 6, 9]))):  # above 3 lights k_shade stages shadow rays light by light
         k = int(r.integers(0, 4))
         pos = r.uniform(-2, 2, 3).astype(F)
         if k == 0:
