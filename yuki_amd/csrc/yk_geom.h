@@ -91,7 +91,11 @@ YK_HD bool slab(V3 lo, V3 hi, V3 o, V3 inv, float t_max, float& tmin) {
 // t = t_scaled / det (triangle.rs:126-139, no conservative t-error test), so a tie hit among
 // coplanar triangles can RAISE t_max by a few ulps, and a box culled at visit time by the
 // exact bound would pass at pop time.  2^-10 relative covers thousands of such raises.
+#ifdef YK_EXACT_DEFERRED_BOUND  // build variant for tests/tools only: the pre-fix behaviour, to show that a test scene exercises the case
+YK_HD float deferred_t_max(float t_max) { return t_max; }
+#else
 YK_HD float deferred_t_max(float t_max) { return t_max * 1.0009765625f; }
+#endif
 
 // SurfaceInteraction after Triangle::intersect, triangle.rs:141-226 +
 // interaction.rs:95-132 — the fields the integrator reads.

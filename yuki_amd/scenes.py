@@ -315,6 +315,35 @@ def glass_balls():
     return s
 
 
+def coplanar_slabs(seed=7):
+    """Regression scene for tie hits that RAISE t_max: three slabs of heavily
+    overlapping random triangles, each slab in one plane (y = -0, x = 0.5, z = -1), so that most
+    rays hit many triangles at distances that differ by rounding only; per-vertex normals make
+    the winner of a tie visible in the shading-normals integrator."""
+    r = np.random.default_rng(seed)
+    pts, nrm, idx, tmesh = [], [], [], []
+    base = 0
+    for mi, (axis, value) in enumerate(((1, -0.0), (0, 0.5), (2, -1.0))):
+        nv, nt = 60, 160
+        p = r.uniform(-1.5, 1.5, (nv, 3)).astype(F)
+        p[:, axis] = F(value)
+        n = r.normal(size=(nv, 3)).astype(F)
+        n /= np.linalg.norm(n, axis=1, keepdims=True).astype(F)
+        pts.append(p)
+        nrm.append(n.astype(F))
+        idx.append(r.integers(0, nv, (nt, 3)).astype(np.uint32) + np.uint32(base))
+        tmesh += [mi] * nt
+        base += nv
+    nt = len(tmesh)
+    l2w, _ = _translation((2.0, 2.5, 1.5))
+    return SceneData(
+        points=np.concatenate(pts), normals=np.concatenate(nrm), indices=np.concatenate(idx), tri_mesh=np.asarray(tmesh, dtype=np.uint32),
+        tri_material=(np.arange(nt) % 3).astype(np.int32), tri_area_light=np.full(nt, -1, dtype=np.int32), meshes=[(True, False, False)] * 3,
+        materials=[dict(kind=abi.MAT_MATTE, a=(0.8, 0.3, 0.2), c=0.0), dict(kind=abi.MAT_MATTE, a=(0.2, 0.7, 0.3), c=0.4), dict(kind=abi.MAT_GLOSSY, a=(0.5, 0.5, 0.9), c=0.3)],
+        lights=[dict(kind="point", l2w=l2w, I=(30.0, 30.0, 30.0))], background=(0.1, 0.1, 0.1), split_method=abi.SPLIT_MIDDLE, max_shapes_in_node=4,
+        camera=dict(position=(2.3, -0.1, -1.3), target=(0.0, 0.0, 0.0), up=(0, 1, 0), fov_axis=abi.FOV_Y, fov_degrees=70.0), name="coplanar-slabs")
+
+
 # --------------------------------------------------------------------------- cfg 2: bunny-class mesh
 def _cube_sphere(n):
     """6 faces x n x n quads; returns unit-sphere points (nv,3) f64 and triangles (nt,3)."""
@@ -546,6 +575,8 @@ def by_name(name):
         return cornell_triangles_only()
     if name == "glass-balls":
         return glass_balls()
+    if name == "coplanar-slabs":
+        return coplanar_slabs()
     if name == "cfg2":
         return bunny_class()
     if name == "cfg3":
