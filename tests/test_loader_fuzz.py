@@ -126,3 +126,16 @@ def test_random_valid_pbrt_files_load_identically(tmp_path, oracle):
     warnings.filterwarnings("ignore", category=RuntimeWarning)  # 1/0 in the oracle's Scale(…, 0) inverse, as in the reference
     for seed in range(7000, 7120):
         assert loader_fuzz.check_seed(seed, str(tmp_path)) is None, seed
+
+
+def test_random_valid_ply_files_load_identically(tmp_path, oracle):
+    """tools/ply_fuzz.py: random PLY files (three encodings, property orders, extra properties and
+    elements of every type, type-name aliases, list count / index types, polygons): both loaders
+    return the same mesh or both reject."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ply_fuzz
+
+    for seed in range(9000, 9200):
+        assert ply_fuzz.check_seed(seed, str(tmp_path)) is None, seed
