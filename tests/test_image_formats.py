@@ -196,3 +196,55 @@ def test_pbrt_scene_with_textures_in_other_containers(tmp_path, oracle):
     assert len(got.textures) == 3
     for a, b in zip(got.textures, base.textures):
         assert a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_images_in_every_container(tmp_path, seed):
+    """Random sizes (1 x 1 up), contents and encoder options for every container: both decoders return the
+    source pixels exactly."""
+    r = np.random.default_rng(seed)
+    w, h = int(r.integers(1, 41)), int(r.integers(1, 31))
+    img = r.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if r.random() < 0.5:
+        img[:, : w // 2] = img[0, 0]  # runs
+    img16 = r.integers(0, 65536, (h, w, 3)).astype(np.int64)
+    d = str(tmp_path)
+    cases = []
+    p = os.path.join(d, "a.bmp")
+    bits = int(r.choice([24, 32]))
+    sf.write_bmp(p, img, bits=bits, top_down=bool(r.integers(0, 2)), header=int(r.choice([40, 52, 56, 108, 124])) if bits == 24 else 40)
+    cases.append((p, _u8(img)))
+    pal = r.integers(0, 256, (int(r.integers(2, 17)), 3), dtype=np.uint8)
+    idx = r.integers(0, len(pal), (h, w), dtype=np.uint8)
+    p = os.path.join(d, "b.bmp")
+    sf.write_bmp(p, idx, bits=int(r.choice([4, 8])), palette=pal, top_down=bool(r.integers(0, 2)))
+    cases.append((p, _u8(pal[idx])))
+    p = os.path.join(d, "a.tga")
+    sf.write_tga(p, img, alpha=bool(r.integers(0, 2)), rle=bool(r.integers(0, 2)), top_left=bool(r.integers(0, 2)), id_field=bytes(r.integers(0, 256, int(r.integers(0, 9)), dtype=np.uint8)))
+    cases.append((p, _u8(img)))
+    p = os.path.join(d, "b.tga")
+    sf.write_tga(p, idx, cmap=pal, rle=bool(r.integers(0, 2)), top_left=bool(r.integers(0, 2)))
+    cases.append((p, _u8(pal[idx])))
+    p = os.path.join(d, "a.ppm")
+    deep = bool(r.integers(0, 2))
+    sf.write_ppm(p, img16 if deep else img, maxval=65535 if deep else 255, ascii=bool(r.integers(0, 2)), comment=bool(r.integers(0, 2)))
+    cases.append((p, (img16 if deep else img).astype(np.float32) / np.float32(65535 if deep else 255)))
+    p = os.path.join(d, "a.qoi")
+    sf.write_qoi(p, img, alpha=r.integers(0, 256, (h, w), dtype=np.uint8) if r.random() < 0.5 else None)
+    cases.append((p, _u8(img)))
+    p = os.path.join(d, "a.ff")
+    sf.write_farbfeld(p, img16)
+    cases.append((p, img16.astype(np.float32) / np.float32(65535.0)))
+    f = (r.random((h, w, 3), dtype=np.float32) * np.float32(r.choice([1.0, 100.0, 1e-3]))).astype(np.float32)
+    half = bool(r.integers(0, 2))
+    if half:
+        f = f.astype(np.float16).astype(np.float32)
+    p = os.path.join(d, "a.exr")
+    sf.write_exr(p, f, compression=int(r.choice([0, 2, 3])), half=half, extra_channels=tuple(r.choice(["A", "Z", "Y"], int(r.integers(0, 3)), replace=False)),
+                 data_origin=(int(r.integers(-9, 9)), int(r.integers(-9, 9))))
+    cases.append((p, f))
+    p = os.path.join(d, "a.png")
+    sf.write_png(p, img.astype(np.int64), alpha=bool(r.integers(0, 2)), interlace=bool(r.integers(0, 2)))
+    cases.append((p, _u8(img)))
+    for path, want in cases:
+        assert _both(path).tobytes() == want.tobytes(), path
