@@ -928,7 +928,10 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
     const unsigned tg = fit(trace_grid(ctx), n_paths), tg_any = fit(trace_grid(ctx), n_shadow_max);
     const unsigned pg_full = (unsigned)ctx->n_cu * packet_blocks_per_cu();
     const unsigned pg = fit(pg_full, n_paths), pg_any = fit(pg_full, n_shadow_max);
-    static const unsigned shade_bpc = std::getenv("YK_SHADE_BPC") ? (unsigned)std::atoi(std::getenv("YK_SHADE_BPC")) : 8u;
+    // k_shade / k_accumulate are grid-stride kernels: 256 blocks per CU (three are resident) let the block
+    // scheduler even out the iterations' very different costs; 8 persistent-style blocks per CU were 2.9 % slower
+    // on the frame (sweep 3..1024: 147.3, 146.9, 148.0 (8), 146.6, 145.4 (24), 145.1 (96), 143.7 (256), 144.2, 144.3 ms)
+    static const unsigned shade_bpc = std::getenv("YK_SHADE_BPC") ? (unsigned)std::atoi(std::getenv("YK_SHADE_BPC")) : 256u;
     const unsigned sg = fit((unsigned)ctx->n_cu * shade_bpc, n_paths);
     const unsigned spill_stride = trace_grid(ctx) * trace_block_size();
     unsigned cur = 0;
