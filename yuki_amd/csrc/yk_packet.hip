@@ -88,7 +88,9 @@ struct PktStack {
 // rays claimed per atomic: up to YK_PKT_CHUNK packets, fewer when the queue is short so that
 // every resident wave makes about eight claims (two claims per wave left the last waves of a
 // 16 M-ray launch with 50 % more work than the rest)
-#define YK_PKT_CHUNK 16
+#ifndef YK_PKT_CHUNK
+#define YK_PKT_CHUNK 16  // packets per claim at most (sweep 4 / 8 / 16 / 32 / 64)
+#endif
 __device__ __forceinline__ unsigned pkt_claim_size(unsigned n) {
     const unsigned waves = gridDim.x * (blockDim.x / YK_WAVE);
     unsigned packets = n / (waves * YK_WAVE * 8u);
