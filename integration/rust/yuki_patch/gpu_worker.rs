@@ -62,7 +62,10 @@ pub fn render_payload(gpu: &Arc<HipDevice>, info: WorkerInfo, payload: &Payload,
     // Accumulating (interactive) mode: one pass is one sample per pixel, too little work for a
     // submission, so PASSES passes (samples t.sample .. t.sample + PASSES - 1) are rendered at
     // once, pass-major in `out`; render_manager.rs:135-143 then re-queues with sample + PASSES.
-    let passes: usize = if payload.accumulate { PASSES } else { 1 };
+    // never beyond the sampler's samples per pixel: the library refuses sample + passes > spp (render_manager.rs:135-143
+    // queues samples 0 .. spp-1 only; past that the stratified permutation is undefined)
+    let left = payload.sampler.samples_per_pixel() as usize - tiles.iter().map(|t| t.sample as usize).max().unwrap_or(0);
+    let passes: usize = if payload.accumulate { PASSES.min(left.max(1)) } else { 1 };
     let mut out = vec![Spectrum::<f32>::zeros(); n_px * passes];
     let (cam, smp, integ) = (camera_desc(&payload.camera), sampler_desc(payload.sampler.as_ref()), integrator_desc(&params));
     let mut stats = sys::yk_render_stats::default();
