@@ -195,6 +195,22 @@ class OracleScene:
         assert rc == 0
         return out, rays.value
 
+    def li(self, sampler, integrator, o, d, pixel_xy, sample_index, dimension=2):
+        """Integrator::li for caller-supplied rays (integrators/mod.rs:94-101); the sampler is started at
+        (pixel, sample_index) and `dimension` one-dimensional draws are consumed first (2 = after the camera sample).  -> (li (n, 3) f32, ray counts (n,) u64)"""
+        o = np.ascontiguousarray(o, dtype=np.float32)
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        pix = np.ascontiguousarray(pixel_xy, dtype=np.uint16)
+        si = np.ascontiguousarray(sample_index, dtype=np.uint32)
+        out = np.zeros((o.shape[0], 3), dtype=np.float32)
+        rays = np.zeros(o.shape[0], dtype=np.uint64)
+        f = lib().orc_li
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        rc = f(self.h, C.cast(C.byref(sampler), C.c_void_p), C.cast(C.byref(integrator), C.c_void_p), o.shape[0], _p(o), _p(d), _p(pix), _p(si), dimension, _p(out), _p(rays))
+        assert rc == 0
+        return out, rays
+
     def intersect(self, o, d, t_max=None):
         o = np.ascontiguousarray(o, dtype=np.float32)
         d = np.ascontiguousarray(d, dtype=np.float32)

@@ -270,6 +270,29 @@ static IntegratorParams integ_from(const orc_integrator_desc* d) {
     return p;
 }
 
+// Integrator::li (integrators/mod.rs:94-101) for caller-supplied rays: the sampler is started at
+// (pixel, sample_index) and `dimension` draws are consumed, as a render leaves it after the camera
+// sample (integrators/mod.rs:152-166), then li runs.  out_li: 3 floats per ray; out_rays: li's ray counts.
+int orc_li(const orc_scene* s, const orc_sampler_desc* smp, const orc_integrator_desc* integ, size_t n, const float* ray_o, const float* ray_d,
+           const uint16_t* pixel_xy, const uint32_t* sample_index, uint32_t dimension, float* out_li, uint64_t* out_rays) {
+    Sampler sampler = sampler_from(smp);
+    IntegratorParams prm = integ_from(integ);
+    for (size_t i = 0; i < n; ++i) {
+        // the state li finds in a render: started at dimension 0, then `dimension` one-dimensional draws consumed
+        // by the caller (two for the camera sample, integrators/mod.rs:152-166)
+        sampler.start_pixel_sample(pixel_xy[2 * i], pixel_xy[2 * i + 1], sample_index[i], 0);
+        for (uint32_t k = 0; k < dimension; ++k) (void)sampler.get_1d();
+        Rayf ray(Point3f(ray_o[3 * i], ray_o[3 * i + 1], ray_o[3 * i + 2]), Vec3f(ray_d[3 * i], ray_d[3 * i + 1], ray_d[3 * i + 2]),
+                 std::numeric_limits<float>::infinity());
+        RadianceResult r = integrator_li(prm, ray, s->scene, sampler, nullptr);
+        out_li[3 * i] = r.li.r;
+        out_li[3 * i + 1] = r.li.g;
+        out_li[3 * i + 2] = r.li.b;
+        if (out_rays) out_rays[i] = r.ray_scene_intersections;
+    }
+    return 0;
+}
+
 }  // extern "C"
 
 static int render_tiles_common(const orc_scene* s, const orc_camera* cam, const orc_sampler_desc* smp, const orc_integrator_desc* integ,

@@ -154,6 +154,9 @@ int orc_render_tiles(const orc_scene* s, const orc_camera* cam, const orc_sample
 int orc_render_tiles_accumulating(const orc_scene* s, const orc_camera* cam, const orc_sampler_desc* smp, const orc_integrator_desc* integ,
                                   const orc_tile* tiles, const uint16_t* tile_samples, size_t n_tiles, float* out_rgb, uint64_t* out_ray_count,
                                   int n_threads);
+/* Integrator::li (integrators/mod.rs:94-101) for caller-supplied rays; the sampler is started at (pixel, sample_index) and `dimension` draws are consumed first */
+int orc_li(const orc_scene* s, const orc_sampler_desc* smp, const orc_integrator_desc* integ, size_t n, const float* ray_o, const float* ray_d,
+           const uint16_t* pixel_xy, const uint32_t* sample_index, uint32_t dimension, float* out_li, uint64_t* out_rays);
 
 /* per-stage entry points */
 void orc_camera_rays(const orc_camera* cam, const orc_sampler_desc* smp, const orc_tile* tile, uint32_t sample_index,

@@ -421,3 +421,53 @@ def test_random_scenes_match_the_oracle(ctx, yk, oracle, seed):
     import parity_fuzz
 
     assert parity_fuzz.check_seed(None, oracle, seed) == []  # None: the context options cycle with the seed (both node layouts, ...)
+
+
+@pytest.mark.parametrize("seed", range(2000, 2016))
+def test_li_on_random_rays_matches_the_oracle(oracle, yk, seed):
+    """Integrator::li (integrators/mod.rs:94-101) for caller-supplied rays on random scenes: yk_li against
+    the oracle's li with the sampler started at (pixel, sample index) and `dimension` draws consumed, Path and Whitted."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import parity_fuzz
+    import stage_fuzz
+
+    ctx = parity_fuzz.variant_context(seed)
+    sd = parity_fuzz.random_scene(seed)
+    r = np.random.default_rng(seed ^ 0x11)
+    o, d = stage_fuzz.rays_for(sd, r, n=600)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)  # li takes the unit directions a camera or a BSDF produces
+    smp = yk.SamplerType.Uniform(5, SEED) if seed % 2 else yk.SamplerType.Stratified((2, 3), True, SEED)
+    pix = r.integers(0, 300, (len(o), 2)).astype(np.uint16)
+    si = r.integers(0, yk.samples_per_pixel(smp), len(o)).astype(np.uint32)
+    dim = int(r.integers(0, 7))
+    sc = yk.Scene(ctx, sd)
+    osc = oracle.OracleScene(sd)
+    for integ in (yk.IntegratorType.Path(yk.PathParams(max_depth=int(r.integers(1, 8)))), yk.IntegratorType.Whitted(int(r.integers(1, 6)))):
+        got = yk.IntegratorType.instantiate(ctx, integ).li(sc, smp, o, d, pix, si, dimension=dim)
+        want, _ = osc.li(smp, integ, o, d, pix, si, dimension=dim)
+        same = (_bits(got) == _bits(want)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), int((~same).sum())
+    sc.close()
+
+
+def test_li_equals_the_render_of_that_sample(ctx, yk, oracle):
+    """li on the camera rays of sample k at dimension 2 == the accumulating render of sample k — with
+    2x2 strata and a uniform sampler of 3, where the stratum hash and the PCG offset both matter
+    (1x1 strata would hide a wrong dimension)."""
+    sd = scenes.by_name("city-tiny")
+    fs = yk.FilmSettings(res=(32, 32), tile_dim=32, accumulate=True)
+    cam = yk.Camera(sd.camera, fs)
+    tiles = yk.film_tiles(fs)
+    sc = yk.Scene(ctx, sd)
+    xy = np.stack(np.meshgrid(np.arange(32), np.arange(32), indexing="xy"), axis=-1).reshape(-1, 2).astype(np.uint16)
+    for sampler in (yk.SamplerType.Uniform(3, SEED), yk.SamplerType.Stratified((2, 2), True, SEED), yk.SamplerType.Stratified((2, 2), False, SEED)):
+        for integ in (yk.IntegratorType.Path(yk.PathParams(max_depth=6)), yk.IntegratorType.Whitted(4)):
+            it = yk.IntegratorType.instantiate(ctx, integ)
+            for k in (0, 2):
+                img, _ = it.render_tiles_accumulating(sc, cam, sampler, tiles, np.full(len(tiles), k, dtype=np.uint16))
+                o, d = yk.camera_rays(ctx, cam, sampler, (0, 0, 32, 32), k)
+                li = it.li(sc, sampler, o, d, xy, np.full(len(o), k, dtype=np.uint32), dimension=2)
+                assert np.array_equal(_bits(li), _bits(img))
