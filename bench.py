@@ -9,7 +9,9 @@ resolve, scene and camera already resident in HBM.  Workload (SURVEY.md §8(d),
 BASELINE.json configs[2], the configuration the >=1 Gray/s target is quoted on):
 ~1 M-triangle synthetic scene, SAH BVH, Path 8 bounces, Stratified 8x8 = 64 spp.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the film's spiral
+N > 1 (one rank per GPU; the driver launches the ranks with torch.distributed.run — when
+WORLD_SIZE is not set, `bench.py --gpus N` starts them itself, as child processes, before this
+process has loaded torch or touched HIP, and relays rank 0's line): the film's spiral
 tile list (film.rs:333-376) is dealt round-robin to the ranks, the scene is
 replicated, each rank renders its tiles into HBM and one RCCL gather moves the
 per-tile radiance to rank 0, which scatters it into the film (Film::update_tile).
@@ -39,8 +41,53 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-GATHER_CEILING_GBPS = 14600.0
 HBM_COPY_CEILING_GBPS = 6290.0
+L2_PEAK_GBPS = 34500.0  # MI355X_MICROARCH.md §L2: ~34.5 TB/s aggregate
+
+
+def self_launch(args):
+    """`--gpus N` (N > 1) without a launcher: start the N ranks as children of this process — which has
+    not imported torch and never touches HIP — relay their output (rank 0 prints the JSON line) and
+    exit with their status.  Never falls through to a one-GPU run."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log(f"[bench] WORLD_SIZE unset: launching {args.gpus} ranks: {' '.join(cmd)}")
+    rc = subprocess.call(cmd, env=env)
+    raise SystemExit(rc)
+
+
+def gather_ceiling(table_bytes):
+    """Measured ceiling of per-lane 64-byte gathers (tools/micro/gather_bench.hip, raw output and parsed
+    table tracked in profiles/): the entry whose table is the smallest one not smaller than `table_bytes`."""
+    best = None
+    for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+        if f.endswith("_gather_bench.json"):
+            best = f  # latest round
+    if best is None:
+        return None
+    d = json.load(open(os.path.join(ROOT, "profiles", best)))
+    rows = sorted(d["tables"], key=lambda r: r["table_bytes"])
+    row = next((r for r in rows if r["table_bytes"] >= table_bytes), rows[-1])
+    return dict(GBps=row["GBps"], table_bytes=row["table_bytes"], source=f"profiles/{best}")
+
+
+def pmc_traffic(workload):
+    """HBM-side bytes per launch of the two traversal kernel families from the latest tracked PMC passes."""
+    best = None
+    for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+        if f.endswith(f"_pmc_{workload}.json") or f == f"pmc_{workload}.json":
+            best = f if best is None or f.startswith("r") else best
+    if best is None:
+        return {}, None
+    return json.load(open(os.path.join(ROOT, "profiles", best))), f"profiles/{best}"
 
 
 def log(*a):
@@ -57,6 +104,12 @@ def workload(name):
     if name == "cfg2":
         return dict(scene="cfg2", res=(1920, 1080), sampler=yk.SamplerType.Uniform(16), depth=8,
                     desc="cfg2: bunny-class 69,312-triangle mesh, SAH BVH, Path 8 bounces, Uniform 16 spp, 1920x1080")
+    if name == "cfg5":
+        return dict(scene="cfg5", res=(3840, 2160), sampler=yk.SamplerType.Stratified((16, 16), True), depth=16,
+                    desc="cfg5: city 100x80 displaced icospheres, 10,240,012 triangles (GGX metal / perfect glass mix), SAH BVH, Path 16 bounces, Stratified 16x16, 3840x2160")
+    if name == "cfg1":
+        return dict(scene="cornell", res=(512, 512), sampler=yk.SamplerType.Uniform(1), depth=3, whitted=True,
+                    desc="cfg1: built-in Cornell box, Whitted depth 3, Uniform 1 spp, 512x512")
     if name == "smoke":
         return dict(scene="city-small", res=(320, 180), sampler=yk.SamplerType.Stratified((2, 2), True), depth=8,
                     desc="smoke: city-small 7,692 triangles, Path 8, Stratified 2x2, 320x180")
@@ -103,6 +156,10 @@ def main():
     ap.add_argument("--rccl-single", action="store_true",
                     help="N=1 through the N>1 code path: a one-rank RCCL process group, asynchronous slots, gather, scatter "
                          "(checks the collective's ordering on the context streams on a single GPU)")
+    ap.add_argument("--gather", choices=["abi", "torch"], default="abi",
+                    help="N>1: who moves the slabs to rank 0 - 'abi': the library's own RCCL exchange (yk_dist_gather: ncclSend/ncclRecv on the "
+                         "rendering context's stream, communicator joined through the C ABI); 'torch': torch.distributed.gather on the nccl backend. "
+                         "'abi' falls back to 'torch' when the communicator cannot be created (reported in config.gather)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 rehearsal on a single GPU: every rank uses cuda:0 and the gather goes through gloo and host memory "
                          "(RCCL refuses two ranks on one device); exercises the N>1 control flow, its number means nothing")
@@ -114,13 +171,20 @@ def main():
                          "the latency tail of step k then overlaps the bulk of step k+1")
     args = ap.parse_args()
 
-    import torch
-
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return; nothing GPU-related has been imported yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
+
+    import torch
+
+    if world > 1 and not args.rehearse_on_one_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} device(s) visible")
     dist = None
     use_dist = world > 1 or args.rccl_single  # the multi-rank control flow (also with one rank, for rehearsal)
     if use_dist:
@@ -138,8 +202,10 @@ def main():
             torch.cuda.set_device(0)
             dist.init_process_group("gloo")
         else:
+            # control plane (barriers, the max over ranks) on gloo / CPU tensors; the nccl (= RCCL) backend serves
+            # `--gather torch` only and creates its communicator lazily, at the first collective on a device tensor
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("cpu:gloo,cuda:nccl")
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -161,7 +227,7 @@ def main():
     fs = yk.FilmSettings(res=wl["res"], tile_dim=16)
     cam = yk.Camera(sd.camera, fs)
     sampler = wl["sampler"]
-    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=wl["depth"]))
+    integ = yk.IntegratorType.Whitted(wl["depth"]) if wl.get("whitted") else yk.IntegratorType.Path(yk.PathParams(max_depth=wl["depth"]))
     it = yk.IntegratorType.instantiate(ctx, integ)
     tiles = yk.film_tiles(fs)
     spp = yk.samples_per_pixel(sampler)
@@ -174,7 +240,14 @@ def main():
     slab_px = ydist.slab_pixels(tiles, world)
     slab = torch.zeros(slab_px * 3, dtype=torch.float32, device=dev)
     film = torch.zeros(wl["res"][1] * wl["res"][0] * 3, dtype=torch.float32, device=dev) if rank == 0 else None
-    gathered = [torch.zeros_like(slab) for _ in range(world)] if (rank == 0 and use_dist) else None
+
+    def gather_buffers():  # rank 0: one allocation, world slabs back to back (what yk_dist_gather fills), and its per-rank views
+        if not (rank == 0 and use_dist):
+            return None, None
+        whole = torch.zeros(world * slab.numel(), dtype=torch.float32, device=dev)
+        return whole, [whole[r * slab.numel():(r + 1) * slab.numel()] for r in range(world)]
+
+    gathered_all, gathered = gather_buffers()
 
     # Prepared tile lists: the pixel tables live on the device, so a step needs no upload.
     my_list = yk.TileList(ctx, my_tiles)
@@ -188,12 +261,43 @@ def main():
     # (late bounces: few rays, every launch as long as its longest ray) runs beside the bulk of
     # step k+1.  Every slot renders the same scene copy and tile list; steps stay ordered per slot.
     in_flight = max(1, args.frames_in_flight or (2 if use_dist else 1)) if async_steps else 1
-    slots = [dict(ctx=ctx, it=it, slab=slab, gathered=gathered, film=film)]
+    slots = [dict(ctx=ctx, it=it, slab=slab, gathered=gathered, gathered_all=gathered_all, film=film)]
     for _ in range(1, in_flight):
         c2 = yk.Context(local_rank, **opts)
-        slots.append(dict(ctx=c2, it=yk.IntegratorType.instantiate(c2, integ), slab=torch.zeros_like(slab),
-                          gathered=[torch.zeros_like(slab) for _ in range(world)] if gathered is not None else None,
+        ga, gl = gather_buffers()
+        slots.append(dict(ctx=c2, it=yk.IntegratorType.instantiate(c2, integ), slab=torch.zeros_like(slab), gathered=gl, gathered_all=ga,
                           film=torch.zeros_like(film) if film is not None else None))
+
+    def cpu_all_reduce(values, op):  # control-plane reduction on the gloo backend
+        t = torch.tensor(values, dtype=torch.float64)
+        dist.all_reduce(t, op=op)
+        return t.tolist()
+
+    # Who carries the slabs: the library's own RCCL exchange (one communicator per slot, joined through the C ABI with an
+    # id that rank 0 publishes in the rendezvous store), torch.distributed's nccl backend, or - rehearsal - gloo.
+    gather_mode = None
+    if use_dist:
+        gather_mode = "gloo-host" if args.rehearse_on_one_gpu else args.gather
+        if gather_mode == "abi":
+            ok = 1.0
+            try:
+                from torch.distributed.distributed_c10d import _get_default_store
+
+                store = _get_default_store()
+                for k, sl in enumerate(slots):
+                    key = f"yk_dist_id_{k}"
+                    if rank == 0:
+                        store.set(key, yk.Dist.unique_id())
+                    sl["dist"] = yk.Dist(sl["ctx"], bytes(store.get(key)), rank, world)
+            except Exception as e:  # noqa: BLE001 - any failure means: use the other carrier, on every rank
+                log(f"[bench] rank {rank}: yk_dist unavailable ({e}); falling back to torch.distributed.gather")
+                ok = 0.0
+            if cpu_all_reduce([ok], dist.ReduceOp.MIN)[0] < 1.0:
+                for sl in slots:
+                    if sl.get("dist"):
+                        sl["dist"].close()
+                        sl["dist"] = None
+                gather_mode = "torch (fallback from abi)"
     # A slot's work — render, RCCL gather, film scatter — is ordered on its context's own stream
     # (torch sees it as an ExternalStream): no further stream takes part, so the main / side stream
     # pairs of the slots are the only busy streams (HIP shares hardware queues between streams).
@@ -219,6 +323,8 @@ def main():
                 if rank == 0:
                     for r in range(world):
                         sl["gathered"][r].copy_(parts[r])
+            elif gather_mode == "abi":  # ncclSend / ncclRecv on the slot's context stream, behind the render
+                sl["dist"].gather(sl["slab"].data_ptr(), sl["gathered_all"].data_ptr() if rank == 0 else 0, sl["slab"].numel())
             else:
                 dist.gather(sl["slab"], sl["gathered"], dst=0)  # RCCL, ordered after the render through torch's current stream = the slot's
             if rank == 0:
@@ -231,7 +337,7 @@ def main():
     def sync():
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
+            cpu_all_reduce([0.0], dist.ReduceOp.SUM)  # barrier
             torch.cuda.synchronize()
 
     if in_flight > 1:  # setup: every slot allocates its work buffers on its first step
@@ -244,6 +350,17 @@ def main():
     sync()
     probe = step() if async_steps else None  # untimed, alone on the GPU: per-step ray counts and kernel timings for the asynchronous mode
     sync()
+    # Roofline probe (rank 0, N = 1): one untimed step with the side stream off, so that every traversal launch runs
+    # alone on the GPU and its HIP-event duration is the kernel's own (in the default mode {any-hit, accumulate}(b)
+    # share the GPU with closest-hit(b+1) and their events include the time they wait for each other).
+    solo = None
+    if world == 1 and not use_dist:
+        ctx.set_option("overlap_shadow", 0)
+        ctx.set_option("streams", 1)  # a frame of several batches: no second work set beside the first either
+        solo = step()
+        sync()
+        ctx.set_option("overlap_shadow", 1)
+        ctx.set_option("streams", 2)
     t0 = time.perf_counter()
     rays = shadow = 0
     t_trace = t_shadow = t_shade = t_dev = 0.0
@@ -261,12 +378,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([rays, shadow], dtype=torch.int64, device=dev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        rays_all, shadow_all = int(c[0].item()), int(c[1].item())
+        elapsed = cpu_all_reduce([elapsed], dist.ReduceOp.MAX)[0]
+        rays_all, shadow_all = (int(v) for v in cpu_all_reduce([rays, shadow], dist.ReduceOp.SUM))
     else:
         rays_all, shadow_all = rays, shadow
 
@@ -312,42 +425,66 @@ def main():
         elif os.path.exists(stored):
             counters = json.load(open(stored))["counters"]
         roofline = None
-        if counters and t_trace > 0:
-            # dominant kernel = k_trace_closest.  Algorithmic bytes per ray it traces:
-            #   32 B per BVH node test + 36 B per leaf triangle test (the oracle's counters
-            #   on this scene/seed) + 32 B ray read + 16 B hit record   
-            b_closest = 32.0 * counters["node_tests_per_ray"] + 36.0 * counters["shape_tests_per_ray"] + 48.0
-            achieved = b_closest * rays / t_trace / 1e9
-            # whole-path figure of SURVEY §8(d): B_ray = 32*N_node + 36*N_tri + 304 with shadow tests attributed
-            b_ray = 32.0 * (counters["node_tests_per_ray"] + counters["shadow_node_tests_per_ray"]) + 36.0 * (counters["shape_tests_per_ray"] + counters["shadow_shape_tests_per_ray"]) + 304.0
-            pmc = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
-            pmc_d = json.load(open(pmc)) if os.path.exists(pmc) else {}
+        if solo is not None and solo.seconds_trace > 0 and solo.trace_launches:
+            # Dominant kernel family = the traversal family with the larger summed duration in the solo probe step.
+            # frac = HBM-side bytes per launch (PMC: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes of this
+            # command, tracked under profiles/) / the family's average launch duration measured live here (HIP events on
+            # the launch stream, side stream off) / 8 TB/s.  FETCH_SIZE counts what leaves L2, Infinity-Cache hits
+            # included, so this is an upper bound on DRAM traffic.  The ALGORITHMIC bytes of SURVEY §8(d) — 32 B per node
+            # test, 36 B per triangle test (oracle counters) — are mostly L1 / LDS / L2 hits, not HBM bytes: they are
+            # reported as `algorithmic`, never as an HBM fraction.
+            pmc_d, pmc_src = pmc_traffic(args.workload)
+            table_bytes = int(info.n_interior) * 64 + int(info.n_shapes) * 48  # what the lanes gather from: 64-B nodes, 48-B triangles
+            ceil_l1 = gather_ceiling(0)
+            ceil_tab = gather_ceiling(table_bytes)
 
-            def family(name, kernels, bytes_total, seconds, n_launch, units, traffic):
-                ach = bytes_total / max(seconds, 1e-12) / 1e9
-                return dict(bound="hbm", kernel=name, kernels=kernels, achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s", frac=ach / HBM_PEAK_GBPS, traffic=traffic,
-                            bytes_per_ray=bytes_total / max(1, units), avg_launch_ms=seconds / max(1, n_launch) * 1e3, launches=n_launch,
-                            rays_per_launch=units / max(1, n_launch), seconds_per_step=seconds / args.steps,
-                            frac_of_copy_ceiling=ach / HBM_COPY_CEILING_GBPS,
-                            # measured ceiling of per-lane 64-byte gathers from an L1/L2-resident table (tools/micro/gather_bench.hip,
-                            # DESIGN.md §4): the unit the traversal kernels are actually bound by
-                            frac_of_gather_ceiling=ach / GATHER_CEILING_GBPS)
+            def family(name, key, kernels, seconds, n_launch, units, alg_bytes):
+                avg_s = seconds / max(1, n_launch)
+                fam = pmc_d.get(key, {})
+                traffic = fam.get("hbm_bytes_per_launch")
+                d = dict(bound="hbm", what="L2-miss (fabric-side) traffic incl. Infinity-Cache hits: PMC FETCH_SIZE x 2 + WRITE_SIZE per launch / live launch duration",
+                         kernel=name, kernels=kernels, achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None, traffic=traffic, traffic_source=pmc_src,
+                         avg_launch_ms=avg_s * 1e3, launches=n_launch, rays_per_launch=units / max(1, n_launch),
+                         timing="one untimed probe step with overlap_shadow=0: every launch alone on the GPU, HIP events on its stream")
+                if traffic:
+                    d["achieved"] = traffic / avg_s / 1e9
+                    d["frac"] = d["achieved"] / HBM_PEAK_GBPS
+                    d["frac_of_copy_ceiling"] = d["achieved"] / HBM_COPY_CEILING_GBPS
+                if alg_bytes:
+                    d["algorithmic"] = dict(bytes_per_launch=alg_bytes / max(1, n_launch), bytes_per_ray=alg_bytes / max(1, units), GBps=alg_bytes / max(seconds, 1e-12) / 1e9,
+                                            note="32 B x node tests + 36 B x triangle tests (oracle counters on the CPU sample) + ray/result records; served mostly from L1/LDS/L2 - not an HBM figure")
+                # the unit that does bind: the CU's vector-memory path.  L1 (TCP) tag lookups per second of the
+                # family against the rate the gather micro-benchmark reaches with an L1-resident table (same counter, same pass).
+                acc = fam.get("tcp_accesses_per_launch")
+                if acc and ceil_l1 and ceil_l1.get("tcp_accesses_per_s"):
+                    rate = acc / avg_s
+                    d["vector_memory"] = dict(achieved=rate * 1e-9, peak=ceil_l1["tcp_accesses_per_s"] * 1e-9, unit="G L1 accesses/s", frac=rate / ceil_l1["tcp_accesses_per_s"],
+                                              source=ceil_l1["source"])
+                if fam.get("l2_read_bytes_per_launch"):
+                    d["l2"] = dict(achieved=fam["l2_read_bytes_per_launch"] / avg_s / 1e9, peak=L2_PEAK_GBPS, unit="GB/s", frac=fam["l2_read_bytes_per_launch"] / avg_s / 1e9 / L2_PEAK_GBPS)
+                return d
 
-            # any-hit family: 32 B per node test + 36 B per triangle test of the shadow rays (the oracle's counters are per
-            # counted ray, so x rays) + 32 B ray read + 4 B slot per shadow ray
-            bytes_any = (32.0 * counters["shadow_node_tests_per_ray"] + 36.0 * counters["shadow_shape_tests_per_ray"]) * rays + 36.0 * shadow
-            fam_closest = family("k_trace_closest", ["k_trace_closest_pt", "k_trace_closest_packet"], b_closest * rays, t_trace, launches, rays,
-                                 pmc_d.get("closest", {}).get("hbm_bytes_per_launch", pmc_d.get("hbm_bytes_per_launch")))
-            fam_any = family("k_trace_any", ["k_trace_any_pt", "k_trace_any_packet"], bytes_any, t_shadow, shadow_launches, shadow,
-                             pmc_d.get("any", {}).get("hbm_bytes_per_launch"))
-            # the dominant kernel family is the one with the larger summed launch duration (HIP events on the launch streams;
-            # any-hit launches share the GPU with the next bounce's closest-hit launch, so their durations include that)
-            roofline, other = (fam_any, fam_closest) if t_shadow > t_trace else (fam_closest, fam_any)
+            alg_closest = alg_any = None
+            if counters:
+                per = solo.rays
+                alg_closest = (32.0 * counters["node_tests_per_ray"] + 36.0 * counters["shape_tests_per_ray"] + 48.0) * per
+                alg_any = (32.0 * counters["shadow_node_tests_per_ray"] + 36.0 * counters["shadow_shape_tests_per_ray"]) * per + 36.0 * solo.shadow_rays
+            fam_closest = family("k_trace_closest", "closest", ["k_trace_closest_pt", "k_trace_closest_packet"], solo.seconds_trace, solo.trace_launches, solo.rays, alg_closest)
+            fam_any = family("k_trace_any", "any", ["k_trace_any_pt", "k_trace_any_packet"], solo.seconds_shadow, solo.shadow_launches, solo.shadow_rays, alg_any)
+            roofline, other = (fam_any, fam_closest) if solo.seconds_shadow > solo.seconds_trace else (fam_closest, fam_any)
             roofline["other"] = other
-            roofline.update(path_bytes_per_ray=b_ray, path_achieved=b_ray * (rays / max(t_dev, 1e-9)) / 1e9,
-                            path_frac=b_ray * (rays / max(t_dev, 1e-9)) / 1e9 / HBM_PEAK_GBPS)
+            roofline["gather_ceiling"] = dict(l1_resident=ceil_l1, at_table_size=ceil_tab, table_bytes=table_bytes,
+                                              note="per-lane 64-byte record gathers, tools/micro/gather_bench.hip")
+            roofline["solo_step"] = dict(ms=solo.seconds_total * 1e3, closest_ms=solo.seconds_trace * 1e3, any_ms=solo.seconds_shadow * 1e3, shade_ms=solo.seconds_shade * 1e3)
+            for f in (roofline, other):  # a fraction above 1 means the model is wrong: refuse to print it
+                for k in ("frac",):
+                    if f.get(k) is not None and f[k] > 1.0:
+                        raise SystemExit(f"[bench] roofline {f['kernel']}.{k} = {f[k]:.3f} > 1")
+                for sub in ("vector_memory", "l2"):
+                    if sub in f and f[sub]["frac"] > 1.0:
+                        raise SystemExit(f"[bench] roofline {f['kernel']}.{sub}.frac = {f[sub]['frac']:.3f} > 1")
         out = {
-            "metric": "Mray/s (primary+secondary), Path integrator @1080p",
+            "metric": "Mray/s (primary+secondary), Path integrator @1080p" if wl["res"] == (1920, 1080) else f"Mray/s (primary+secondary), {'Whitted' if wl.get('whitted') else 'Path'} integrator @{wl['res'][0]}x{wl['res'][1]}",
             "value": value,
             "unit": "Mray/s",
             "n_gpus": world,
@@ -361,6 +498,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["desc"], "triangles": sd.n_triangles, "spp": spp, "max_depth": wl["depth"], "tiles": int(len(tiles)),
                        "partition": f"spiral tiles dealt round-robin to {world} rank(s), RCCL gather to rank 0" if use_dist else "single GPU",
+                       "gather": {"abi": "yk_dist_gather (C ABI: ncclSend/ncclRecv on the context stream)", None: None}.get(gather_mode, gather_mode),
                        "frames_in_flight": in_flight},
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -372,6 +510,9 @@ def main():
                       else "synchronous (per-kernel HIP-event times read after every step of the timed region)"},
         }
         print(json.dumps(out), flush=True)
+    for sl in slots:  # communicators first: they hold their context
+        if sl.get("dist"):
+            sl["dist"].close()
     scene.close()
     for sl in slots:
         sl["ctx"].close()

@@ -373,6 +373,68 @@ yk_status yk_bsdf_sample(yk_context* ctx, const yk_material_desc* material, size
 
 size_t yk_sizeof(int what);
 
+/* ---- several GPUs ------------------------------------------------------
+ * The reference renders from ONE process: RenderManager spawns its workers
+ * (renderer/render_manager.rs:78-97), hands out the film's tiles — "interleave tiles" is its own
+ * TODO (render_manager.rs:206-210) — and every finished tile is written back by
+ * Film::update_tile (film.rs:210-282).  yk_multi is that for the GPUs of a node:
+ *   - one context and one host thread per device (the thread enqueues that device's render);
+ *   - the scene's BVH is built once on the host and copied to every device;
+ *   - tile i of the film's outward spiral (film.rs:333-376) belongs to device i mod G; every
+ *     device renders its tiles into a dense tile-major slab in its own HBM;
+ *   - ONE exchange: the slabs move into device 0's memory with RCCL point-to-point calls
+ *     (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd — a gather: tiles are disjoint, so
+ *     nothing is reduced) issued on the contexts' own streams, i.e. ordered after each render
+ *     without host synchronisation; xGMI links are point to point, every slab takes its own;
+ *   - device 0 scatters the slabs into the row-major film (Film::update_tile).
+ * Results are bit for bit those of a single-device render of the same film.
+ * RCCL is loaded on first use (dlopen: a process that already has it — PyTorch — shares it);
+ * without it yk_multi_create on more than one device returns YK_ERR_UNSUPPORTED. */
+typedef struct yk_multi yk_multi;
+typedef struct yk_multi_scene yk_multi_scene;
+typedef struct yk_multi_film yk_multi_film;
+/* devices: HIP ordinals, devices[0] assembles the film.  n_devices == 1 is a plain one-GPU
+ * render through the same code (no communicator unless "rccl_loopback" is set). */
+yk_status yk_multi_create(const int* devices, uint32_t n_devices, yk_multi** out);
+void yk_multi_destroy(yk_multi* m);
+uint32_t yk_multi_device_count(const yk_multi* m);
+/* The context of rank r (options, yk_last_error); owned by the yk_multi. */
+yk_context* yk_multi_context(yk_multi* m, uint32_t rank);
+/* yk_context_set_option on every context; plus "rccl_loopback" (0 | 1): rank 0's own slab also
+ * takes the ncclSend/ncclRecv path (to itself) — exercises the collective on a single GPU. */
+yk_status yk_multi_set_option(yk_multi* m, const char* key, int64_t value);
+yk_status yk_multi_last_error(const yk_multi* m, char* buf, size_t cap);
+/* BoundingVolumeHierarchy::new once, one copy per device. */
+yk_status yk_multi_scene_create(yk_multi* m, const yk_scene_desc* desc, yk_multi_scene** out);
+void yk_multi_scene_destroy(yk_multi_scene* scene);
+yk_status yk_multi_scene_get_info(const yk_multi_scene* scene, yk_scene_info* out);
+/* The film (film.rs:67-113) and its tile queue: film_tiles(res, tile_dim) dealt round-robin,
+ * prepared per device (yk_tile_list), slabs, and the row-major RGB film in device 0's memory. */
+yk_status yk_multi_film_create(yk_multi* m, uint16_t res_x, uint16_t res_y, uint16_t tile_dim, yk_multi_film** out);
+void yk_multi_film_destroy(yk_multi_film* film);
+/* device-0 pointer to res_x * res_y RGB float triples, row-major */
+void* yk_multi_film_device_ptr(const yk_multi_film* film);
+/* Render the whole film.  film_rgb: host buffer (res_x * res_y * 3 floats) or NULL; stats: sums
+ * over the devices (seconds: the slowest device) or NULL.  With both NULL the call only
+ * enqueues work (renders, exchange, scatter) and returns: yk_multi_sync waits for it, after
+ * which yk_multi_film_device_ptr holds the frame.  cancel is polled by every device's render. */
+yk_status yk_multi_render_film(yk_multi* m, const yk_multi_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                               const yk_integrator_desc* integrator, yk_multi_film* film, float* film_rgb, yk_render_stats* stats,
+                               yk_cancel_fn cancel, void* user);
+yk_status yk_multi_sync(yk_multi* m);
+
+/* One process per GPU (MPI-style hosts, torch.distributed launchers): the same exchange between
+ * processes.  Rank 0 obtains an id (ncclGetUniqueId) and hands it to the other ranks by its own
+ * means; every rank then joins with its context (ncclCommInitRank).  yk_dist_gather moves
+ * `count` floats from every rank's d_send into rank 0's d_recv[rank * count ...] on `stream`
+ * (NULL: the context's stream), without host synchronisation; d_recv is ignored elsewhere. */
+#define YK_DIST_ID_BYTES 128
+typedef struct yk_dist yk_dist;
+yk_status yk_dist_unique_id(uint8_t id[YK_DIST_ID_BYTES]);
+yk_status yk_dist_create(yk_context* ctx, const uint8_t id[YK_DIST_ID_BYTES], uint32_t rank, uint32_t world, yk_dist** out);
+void yk_dist_destroy(yk_dist* dist);
+yk_status yk_dist_gather(yk_dist* dist, const void* d_send, void* d_recv, size_t count, void* stream);
+
 /* ---- scene input -------------------------------------------
  * The reference's loaders, host-only (no device needed): they produce the flattened
  * scene description yk_scene_create consumes plus the camera and film settings the

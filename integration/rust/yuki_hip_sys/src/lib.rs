@@ -210,6 +210,10 @@ pub enum yk_context {}
 pub enum yk_scene {}
 pub enum yk_loaded_scene {}
 pub enum yk_tile_list {}
+pub enum yk_multi {}
+pub enum yk_multi_scene {}
+pub enum yk_multi_film {}
+pub enum yk_dist {}
 pub type yk_cancel_fn = Option<unsafe extern "C" fn(user: *mut c_void) -> c_int>;
 
 extern "C" {
@@ -255,6 +259,25 @@ extern "C" {
     pub fn yk_loaded_scene_get(loaded: *const yk_loaded_scene, desc: *mut yk_scene_desc, camera: *mut yk_camera_params, tile_dim: *mut u16) -> yk_status;
     pub fn yk_loaded_scene_destroy(loaded: *mut yk_loaded_scene);
     pub fn yk_loader_last_error() -> *const c_char;
+    // several GPUs of one process (RenderManager's role for GPU workers) and one process per GPU
+    pub fn yk_multi_create(devices: *const c_int, n_devices: u32, out: *mut *mut yk_multi) -> yk_status;
+    pub fn yk_multi_destroy(m: *mut yk_multi);
+    pub fn yk_multi_device_count(m: *const yk_multi) -> u32;
+    pub fn yk_multi_context(m: *mut yk_multi, rank: u32) -> *mut yk_context;
+    pub fn yk_multi_set_option(m: *mut yk_multi, key: *const c_char, value: i64) -> yk_status;
+    pub fn yk_multi_last_error(m: *const yk_multi, buf: *mut c_char, cap: usize) -> yk_status;
+    pub fn yk_multi_scene_create(m: *mut yk_multi, desc: *const yk_scene_desc, out: *mut *mut yk_multi_scene) -> yk_status;
+    pub fn yk_multi_scene_destroy(scene: *mut yk_multi_scene);
+    pub fn yk_multi_scene_get_info(scene: *const yk_multi_scene, out: *mut yk_scene_info) -> yk_status;
+    pub fn yk_multi_film_create(m: *mut yk_multi, res_x: u16, res_y: u16, tile_dim: u16, out: *mut *mut yk_multi_film) -> yk_status;
+    pub fn yk_multi_film_destroy(film: *mut yk_multi_film);
+    pub fn yk_multi_film_device_ptr(film: *const yk_multi_film) -> *mut c_void;
+    pub fn yk_multi_render_film(m: *mut yk_multi, scene: *const yk_multi_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, film: *mut yk_multi_film, film_rgb: *mut f32, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
+    pub fn yk_multi_sync(m: *mut yk_multi) -> yk_status;
+    pub fn yk_dist_unique_id(id: *mut u8) -> yk_status;
+    pub fn yk_dist_create(ctx: *mut yk_context, id: *const u8, rank: u32, world: u32, out: *mut *mut yk_dist) -> yk_status;
+    pub fn yk_dist_destroy(dist: *mut yk_dist);
+    pub fn yk_dist_gather(dist: *mut yk_dist, d_send: *const c_void, d_recv: *mut c_void, count: usize, stream: *mut c_void) -> yk_status;
 }
 
 /// `yk_last_error` as a `String` (empty when none).

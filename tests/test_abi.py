@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_every_declared_symbol_is_exported_and_bound():
     hdr = open(os.path.join(ROOT, "include", "yuki_hip.h")).read()
-    declared = set(re.findall(r"^(?:yk_status|void\*?|size_t|uint32_t|const char\*)\s+(yk_[a-z0-9_]+)\s*\(", hdr, re.M))
+    declared = set(re.findall(r"^(?:yk_status|void\*?|size_t|uint32_t|const char\*|yk_context\*)\s+(yk_[a-z0-9_]+)\s*\(", hdr, re.M))
     assert len(declared) >= 25
     L = _ffi.lib()
     for name in sorted(declared):

@@ -471,3 +471,111 @@ def test_li_equals_the_render_of_that_sample(ctx, yk, oracle):
                 o, d = yk.camera_rays(ctx, cam, sampler, (0, 0, 32, 32), k)
                 li = it.li(sc, sampler, o, d, xy, np.full(len(o), k, dtype=np.uint32), dimension=2)
                 assert np.array_equal(_bits(li), _bits(img))
+
+
+def test_deep_tree_overflow_is_reported_by_every_entry_point(yk, oracle):
+    """bvh.rs:172-174 asserts on a traversal stack of more than 64 entries; the library returns
+    YK_ERR_STACK_OVERFLOW.  The flag has to survive the per-batch reset of the control block (a render of
+    four batches on one work set), reach callers that ask for no statistics (the asynchronous device entry)
+    and yk_li.  A tree of depth 60 built the same way renders, and equals the oracle bit for bit."""
+    import torch
+
+    c = yk.Context(0, batch_paths=4096, streams=1)
+    fs = yk.FilmSettings(res=(64, 64))
+    tiles = yk.film_tiles(fs)
+    smp = yk.SamplerType.Uniform(4, SEED)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=3))
+    it = yk.IntegratorType.instantiate(c, integ)
+
+    sd = scenes.by_name("deep-chain-60")
+    cam = yk.Camera(sd.camera, fs)
+    sc = yk.Scene(c, sd)
+    assert sc.info().tree_depth == 60
+    got, st = it.render_tiles(sc, cam, smp, tiles)
+    want, rays = oracle.OracleScene(sd).render_tiles(cam.matrices, smp, integ, tiles, n_threads=0)
+    assert st.batches == 4 and st.rays == rays and np.array_equal(_bits(got), _bits(want))
+    sc.close()
+
+    sd = scenes.by_name("deep-chain-70")
+    sc = yk.Scene(c, sd)
+    assert sc.info().tree_depth == 70
+    with pytest.raises(yk.YukiError) as e:
+        it.render_tiles(sc, cam, smp, tiles)
+    assert e.value.status == 8
+    out = torch.zeros(64 * 64 * 3, dtype=torch.float32, device="cuda:0")
+    with pytest.raises(yk.YukiError) as e:  # stats == NULL: the call may not stay asynchronous for such a tree
+        it.render_tiles_device(sc, cam, smp, tiles, out.data_ptr(), want_stats=False)
+    assert e.value.status == 8
+    o, d = yk.camera_rays(c, cam, smp, (24, 24, 40, 40), 0)
+    xy = np.stack(np.meshgrid(np.arange(24, 40), np.arange(24, 40), indexing="xy"), axis=-1).reshape(-1, 2).astype(np.uint16)
+    with pytest.raises(yk.YukiError) as e:
+        it.li(sc, smp, o, d, xy, np.zeros(len(o), dtype=np.uint32), dimension=2)
+    assert e.value.status == 8
+    for integ2 in (yk.IntegratorType.Whitted(3), yk.IntegratorType.GeometryNormals):
+        with pytest.raises(yk.YukiError) as e:
+            yk.IntegratorType.instantiate(c, integ2).render_tiles(sc, cam, smp, tiles)
+        assert e.value.status == 8
+    with pytest.raises(yk.YukiError) as e:
+        sc.intersect(o, d)
+    assert e.value.status == 8
+    sc.close()
+    c.close()
+
+
+def _full_size_checks(ctx, yk, oracle, sd, res, sampler, integ, k_oracle, shard=(3, 8), expect_samples=None):
+    """A BASELINE configuration at its full size: (1) the first `k_oracle` spiral tiles at full spp against the oracle,
+    bit for bit, with the oracle's ray count; (2) size-independent properties of the whole frame: the shard of one
+    rank of G equals the same tiles of the full render, bit for bit, and carries about 1/G of the rays."""
+    fs = yk.FilmSettings(res=res, tile_dim=16)
+    cam = yk.Camera(sd.camera, fs)
+    tiles = yk.film_tiles(fs)
+    it = yk.IntegratorType.instantiate(ctx, integ)
+    sc = yk.Scene(ctx, sd)
+    full, st_full = it.render_tiles(sc, cam, sampler, tiles)
+    assert np.isfinite(full).all()
+    if expect_samples is not None:
+        assert st_full.samples == expect_samples
+    offs = np.concatenate([[0], np.cumsum((tiles["x1"].astype(np.int64) - tiles["x0"]) * (tiles["y1"].astype(np.int64) - tiles["y0"]))])
+    osc = oracle.OracleScene(sd)
+    want, rays = osc.render_tiles(cam.matrices, sampler, integ, tiles[:k_oracle], n_threads=0)
+    osc.close()
+    got = full[: offs[k_oracle]]
+    assert _rmse(got, want) < TOL_RMSE
+    assert np.array_equal(_bits(got), _bits(want))
+    head, st_head = it.render_tiles(sc, cam, sampler, tiles[:k_oracle])
+    assert st_head.rays == rays and np.array_equal(_bits(head), _bits(got))
+    r, G = shard
+    idx = np.arange(r, len(tiles), G)
+    part, st = it.render_tiles(sc, cam, sampler, tiles[idx])
+    ref = np.concatenate([full[offs[t] : offs[t + 1]] for t in idx])
+    assert np.array_equal(_bits(part), _bits(ref))
+    assert 0.8 / G < st.rays / st_full.rays < 1.25 / G
+    sc.close()
+    return st_full
+
+
+def test_cfg1_whitted_at_full_size(ctx, yk, oracle):
+    """BASELINE configs[0]: built-in Cornell box (scene/mod.rs:154-530), Whitted depth 3, Uniform 1 spp, 512x512 —
+    the whole frame against the oracle (262,144 camera samples)."""
+    sd = scenes.by_name("cornell")
+    sampler = yk.SamplerType.Uniform(1, SEED)
+    integ = yk.IntegratorType.Whitted(3)
+    got, stats, want, rays = _render_both(ctx, yk, oracle, sd, (512, 512), sampler, integ)
+    assert stats.samples == 512 * 512 and stats.rays == rays
+    assert want.max() > 0 and _rmse(got, want) < TOL_RMSE
+    assert np.array_equal(_bits(got), _bits(want))
+
+
+def test_cfg2_at_full_size(ctx, yk, oracle):
+    """BASELINE configs[1]: bunny-class 69,312-triangle mesh (the reference's PLY defaults: white matte, one point
+    light, scene/mod.rs:104-125), Path 8, Uniform 16 spp, 1920x1080."""
+    _full_size_checks(ctx, yk, oracle, scenes.by_name("cfg2"), (1920, 1080), yk.SamplerType.Uniform(16, SEED), yk.IntegratorType.Path(yk.PathParams(max_depth=8)),
+                      k_oracle=192, expect_samples=1920 * 1080 * 16)
+
+
+def test_cfg5_at_full_size(ctx, yk, oracle):
+    """BASELINE configs[4] on one GPU: 10,240,012 triangles (GGX metal / perfect glass), SAH BVH, Path 16 bounces,
+    Stratified 16x16 = 256 spp, 3840x2160 — 2.1 G camera samples in 16 batches on two work sets."""
+    st = _full_size_checks(ctx, yk, oracle, scenes.by_name("cfg5"), (3840, 2160), yk.SamplerType.Stratified((16, 16), True, SEED),
+                           yk.IntegratorType.Path(yk.PathParams(max_depth=16)), k_oracle=16, expect_samples=3840 * 2160 * 256)
+    assert st.batches >= 2

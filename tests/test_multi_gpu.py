@@ -1,0 +1,87 @@
+"""Several GPUs behind the C ABI (include/yuki_hip.h, yk_multi_* / yk_dist_*): what a single Rust process needs in
+place of render_manager.rs:78-97,206-210 + film.rs:210-282.  On the one-GPU test box the device list is [0]; the RCCL
+exchange itself is exercised by `rccl_loopback` (rank 0's slab takes ncclSend/ncclRecv to itself inside the same group
+call the G > 1 case uses) and by a one-rank yk_dist communicator.  The N-rank case runs in the driver's scaling bench."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from yuki_amd import scenes
+
+pytestmark = pytest.mark.gpu
+SEED = 0x73B9642E74AC471C
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _single(yk, ctx, sd, fs, sampler, integ):
+    cam = yk.Camera(sd.camera, fs)
+    tiles = yk.film_tiles(fs)
+    sc = yk.Scene(ctx, sd)
+    rgb, st = yk.IntegratorType.instantiate(ctx, integ).render_tiles(sc, cam, sampler, tiles)
+    sc.close()
+    return yk.update_tiles(tiles, rgb, fs.res), st, cam
+
+
+@pytest.mark.parametrize("loopback", [0, 1])
+def test_multi_film_equals_the_single_device_render(ctx, yk, oracle, loopback):
+    sd = scenes.by_name("city-small")
+    fs = yk.FilmSettings(res=(200, 120), tile_dim=16)  # ragged right and bottom tiles
+    sampler = yk.SamplerType.Stratified((2, 2), True, SEED)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=6))
+    want, st1, cam = _single(yk, ctx, sd, fs, sampler, integ)
+    m = yk.Multi([0], rccl_loopback=loopback)
+    msc = m.scene(sd)
+    film = m.film(fs)
+    got, st = m.render_film(msc, cam, sampler, integ, film)
+    assert st.rays == st1.rays and st.samples == 200 * 120 * 4
+    assert np.array_equal(_bits(got), _bits(want))
+    # the oracle's render of the same film (whole frame, host-side Film::update_tile)
+    owant, orays = oracle.OracleScene(sd).render_tiles(cam.matrices, sampler, integ, yk.film_tiles(fs), n_threads=0)
+    assert orays == st.rays and np.array_equal(_bits(got), _bits(yk.update_tiles(yk.film_tiles(fs), owant, fs.res)))
+    # asynchronous submission: nothing read back by the call; the frame is in device 0's film after yk_multi_sync
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemset(C.c_void_p(film.device_ptr), 0, C.c_size_t(got.nbytes))
+    hip.hipDeviceSynchronize()
+    none, nost = m.render_film(msc, cam, sampler, integ, film, want_host=False, want_stats=False)
+    assert none is None and nost is None
+    m.sync()
+    back = np.zeros_like(got)
+    assert hip.hipMemcpy(back.ctypes.data_as(C.c_void_p), C.c_void_p(film.device_ptr), C.c_size_t(back.nbytes), 2) == 0
+    assert np.array_equal(_bits(back), _bits(want))
+    film.close()
+    msc.close()
+    m.close()
+
+
+def test_multi_argument_errors(yk):
+    with pytest.raises(yk.YukiError):
+        yk.Multi([])
+    with pytest.raises(yk.YukiError):
+        yk.Multi([0, 0])  # one rank per GPU
+    with pytest.raises(yk.YukiError):
+        yk.Multi([97])
+    m = yk.Multi([0])
+    with pytest.raises(yk.YukiError):
+        m.set_option("no_such_option", 1)
+    with pytest.raises(yk.YukiError):
+        m.film(yk.FilmSettings(res=(0, 16)))
+    m.close()
+
+
+def test_dist_one_rank_gather(ctx, yk):
+    """yk_dist_*: ncclGetUniqueId -> ncclCommInitRank -> grouped ncclSend/ncclRecv on the context's stream."""
+    import torch
+
+    d = yk.Dist(ctx, yk.Dist.unique_id(), 0, 1)
+    src = torch.arange(4096, dtype=torch.float32, device="cuda:0") * 0.5
+    dst = torch.zeros_like(src)
+    torch.cuda.synchronize()
+    d.gather(src.data_ptr(), dst.data_ptr(), src.numel())
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamSynchronize(C.c_void_p(ctx.stream_handle))
+    assert torch.equal(src, dst)
+    d.close()

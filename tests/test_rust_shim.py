@@ -11,7 +11,7 @@ def _c_header():
     s = open(os.path.join(ROOT, "include", "yuki_hip.h")).read()
     s = re.sub(r"/\*.*?\*/", "", s, flags=re.S)
     funcs = {}
-    for m in re.finditer(r"^(?:yk_status|size_t|void\*?|const char\*|uint32_t)\s+(yk_\w+)\(([^;]*?)\);", s, flags=re.M | re.S):
+    for m in re.finditer(r"^(?:yk_status|size_t|void\*?|const char\*|uint32_t|yk_context\*)\s+(yk_\w+)\(([^;]*?)\);", s, flags=re.M | re.S):
         args = m.group(2).strip()
         funcs[m.group(1)] = 0 if args in ("void", "") else len(args.split(","))
     structs = {}

@@ -4,7 +4,9 @@
 //           16k + l/4, so the four lanes of a quad hit one 64-byte record
 //   mode 2: as 1, then exchanged through LDS (ds_write_b128 / ds_read_b128) so that every lane
 //           ends up with its own record
-// Table size is a parameter (fits L2 / Infinity Cache / HBM).  Prints records/s.
+//   modes 3-7 (mode 0 with part of the wave masked off; what does a partially filled gather cost?):
+//     3: lanes 0-31   4: even lanes   5: lanes 0-15   6: one lane per quad (lane % 4 == 0)   7: a random half, new every iteration
+// Table size is a parameter (fits L2 / Infinity Cache / HBM).  Prints records/s (records actually fetched).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -22,8 +24,14 @@ template <int MODE> __global__ __launch_bounds__(256, 6) void k(const float4* __
     float acc = 0.0f;
     for (unsigned it = 0; it < iters; ++it) {
         unsigned idx = rng(s) % n_rec;
-        float4 r0, r1, r2, r3;
-        if (MODE == 0) {
+        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+        if (MODE >= 3) {
+            const bool on = MODE == 3 ? lane < 32u : MODE == 4 ? (lane & 1u) == 0u : MODE == 5 ? lane < 16u : MODE == 6 ? (lane & 3u) == 0u : ((idx >> 13) & 1u) != 0u;
+            if (on) {
+                const float4* p = table + (size_t)idx * 4;
+                r0 = p[0]; r1 = p[1]; r2 = p[2]; r3 = p[3];
+            }
+        } else if (MODE == 0) {
             const float4* p = table + (size_t)idx * 4;
             r0 = p[0]; r1 = p[1]; r2 = p[2]; r3 = p[3];
         } else {
@@ -58,7 +66,8 @@ int main(int argc, char** argv) {
     hipMemset(table, 0, (size_t)n_rec * 64);
     const int grid = 256 * 6;
     hipMalloc(&out, grid * 256 * 4);
-    for (int mode = 0; mode < 3; ++mode) {
+    const double active[8] = {1.0, 1.0, 1.0, 0.5, 0.5, 0.25, 0.25, 0.5};
+    for (int mode = 0; mode < 8; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEvent_t a, b;
             hipEventCreate(&a); hipEventCreate(&b);
@@ -66,11 +75,17 @@ int main(int argc, char** argv) {
             if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
             if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
             if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
+            if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
+            if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
+            if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
+            if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
+            if (mode == 7) hipLaunchKernelGGL(k<7>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
             hipEventRecord(b);
             hipEventSynchronize(b);
             float ms;
             hipEventElapsedTime(&ms, a, b);
-            if (rep) printf("table %zu KB (%zu MB) mode %d: %.3f ms  %.2f G records/s  %.2f TB/s\n", kb, mb, mode, ms, (double)grid * 256 * iters / ms * 1e-6, (double)grid * 256 * iters * 64 / ms * 1e-9);
+            if (rep) printf("table %zu KB (%zu MB) mode %d: %.3f ms  %.2f G records/s  %.2f TB/s  %.2f G wave-instr/s\n", kb, mb, mode, ms, active[mode] * grid * 256 * iters / ms * 1e-6,
+                            active[mode] * grid * 256 * iters * 64 / ms * 1e-9, (double)grid * 4 * iters * 4 / ms * 1e-6);
         }
     }
     return 0;

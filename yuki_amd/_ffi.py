@@ -119,6 +119,25 @@ SYMBOLS = {
     "yk_film_accumulate_tile_list_passes_device": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint16, C.c_uint16, vp, vp]),
     "yk_write_exr": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, vp]),
     "yk_write_pfm": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, vp]),
+    # several GPUs
+    "yk_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_uint32, C.POINTER(vp)]),
+    "yk_multi_destroy": (None, [vp]),
+    "yk_multi_device_count": (C.c_uint32, [vp]),
+    "yk_multi_context": (vp, [vp, C.c_uint32]),
+    "yk_multi_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+    "yk_multi_last_error": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
+    "yk_multi_scene_create": (C.c_int, [vp, C.POINTER(abi.SceneDesc), C.POINTER(vp)]),
+    "yk_multi_scene_destroy": (None, [vp]),
+    "yk_multi_scene_get_info": (C.c_int, [vp, C.POINTER(SceneInfo)]),
+    "yk_multi_film_create": (C.c_int, [vp, C.c_uint16, C.c_uint16, C.c_uint16, C.POINTER(vp)]),
+    "yk_multi_film_destroy": (None, [vp]),
+    "yk_multi_film_device_ptr": (vp, [vp]),
+    "yk_multi_render_film": (C.c_int, [vp, vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), vp, vp, C.POINTER(RenderStats), vp, vp]),
+    "yk_multi_sync": (C.c_int, [vp]),
+    "yk_dist_unique_id": (C.c_int, [vp]),
+    "yk_dist_create": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+    "yk_dist_destroy": (None, [vp]),
+    "yk_dist_gather": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
 }
 
 

@@ -301,6 +301,140 @@ class Scene:
         return out
 
 
+# --------------------------------------------------------------------------- several GPUs
+def _mcheck(status, m):
+    if status != _ffi.YK_OK:
+        buf = C.create_string_buffer(512)
+        lib().yk_multi_last_error(m, buf, 512)
+        raise YukiError(status, buf.value.decode(errors="replace") or lib().yk_status_string(status).decode())
+
+
+class Multi:
+    """The GPUs of one process (yk_multi): a context and a host thread per device; tiles of the
+    film's spiral are dealt round-robin (render_manager.rs:206-210), the slabs meet on devices[0]
+    through RCCL and Film::update_tile runs there."""
+
+    def __init__(self, devices, **options):
+        devices = [int(d) for d in devices]
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        check(lib().yk_multi_create(arr, len(devices), C.byref(h)))
+        self.h = h
+        self.devices = devices
+        for k, v in options.items():
+            self.set_option(k, v)
+
+    def set_option(self, key, value):
+        _mcheck(lib().yk_multi_set_option(self.h, key.encode(), int(value)), self.h)
+
+    def scene(self, scene_data):
+        return MultiScene(self, scene_data)
+
+    def film(self, settings):
+        return MultiFilm(self, settings)
+
+    def render_film(self, scene, camera, sampler, integrator, film, want_host=True, want_stats=True, cancel=None):
+        """Integrator::render for every tile of the film on its device, exchange, Film::update_tile.
+        Returns (film (h, w, 3) float32 or None, RenderStats or None)."""
+        out = np.zeros((film.res[1], film.res[0], 3), dtype=np.float32) if want_host else None
+        stats = RenderStats() if want_stats else None
+        cb = _ffi.CANCEL_FN(lambda _u: 1 if cancel() else 0) if cancel else None
+        _mcheck(
+            lib().yk_multi_render_film(self.h, scene.h, C.byref(camera.matrices), C.byref(sampler), C.byref(integrator), film.h, _p(out), C.byref(stats) if want_stats else None, C.cast(cb, C.c_void_p) if cb else None, None),
+            self.h,
+        )
+        return out, stats
+
+    def sync(self):
+        _mcheck(lib().yk_multi_sync(self.h), self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().yk_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiScene:
+    def __init__(self, multi, scene_data):
+        self.multi = multi
+        d, keep = scene_data.desc(LightFactory)
+        h = C.c_void_p()
+        _mcheck(lib().yk_multi_scene_create(multi.h, C.byref(d), C.byref(h)), multi.h)
+        self.h = h
+
+    def info(self):
+        i = SceneInfo()
+        check(lib().yk_multi_scene_get_info(self.h, C.byref(i)))
+        return i
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().yk_multi_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiFilm:
+    def __init__(self, multi, settings):
+        self.multi = multi
+        self.res = tuple(settings.res)
+        h = C.c_void_p()
+        _mcheck(lib().yk_multi_film_create(multi.h, settings.res[0], settings.res[1], settings.tile_dim, C.byref(h)), multi.h)
+        self.h = h
+
+    @property
+    def device_ptr(self):
+        return int(lib().yk_multi_film_device_ptr(self.h) or 0)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().yk_multi_film_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Dist:
+    """One process per GPU (yk_dist): join an RCCL communicator with this rank's context; gather()
+    moves every rank's slab into rank 0's buffer on the context's stream."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(lib().yk_dist_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self.ctx = ctx
+        idb = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        check(lib().yk_dist_create(ctx.h, idb, rank, world, C.byref(h)), ctx.h)
+        self.h, self.rank, self.world = h, rank, world
+
+    def gather(self, d_send_ptr, d_recv_ptr, count_floats, stream=None):
+        check(lib().yk_dist_gather(self.h, C.c_void_p(d_send_ptr), C.c_void_p(d_recv_ptr) if d_recv_ptr else None, count_floats, C.c_void_p(stream) if stream else None), self.ctx.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().yk_dist_destroy(self.h)
+            self.h = None
+
+
 # --------------------------------------------------------------------------- integrators
 class Integrator:
     """trait Integrator (integrators/mod.rs:92-186) over the HIP wavefront."""

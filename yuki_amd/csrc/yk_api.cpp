@@ -19,115 +19,7 @@
 #include <string>
 #include <vector>
 
-#include "yk_device.h"
-#include "yk_host.h"
-#include "yk_kernels.h"
-
-using namespace yk;
-
-// ------------------------------------------------------------------ helpers
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    hipError_t ensure(size_t want) {
-        if (want <= bytes) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) bytes = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-    }
-    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
-struct yk_context {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string last_error;
-    int n_cu = 256;
-    // options
-    int64_t batch_paths = 128 << 20;
-    int64_t packet_bounces = 1;         // leading bounces whose closest-hit rays use the wave-packet kernel (camera rays are coherent); 0 = never
-    int64_t packet_shadow_bounces = 1;  // same for the shadow rays towards point / spot / distant lights (their own queue)
-    int64_t shade_reorder = 1;   // deal the paths of a shade block to its lanes sorted by material kind (bounces > 0)
-    int64_t overlap_shadow = 1;  // run {trace_any, accumulate}(b) on a side stream beside trace_closest(b+1)
-    int64_t wide_bvh = 2;   // scenes created afterwards: 0 binary nodes only, 1 traverse the 4-wide collapse, 2 keep both and pick per job
-    int64_t top_nodes = YK_TOP_MAX; // interior nodes (capped by what the kernels were built for) of the first tree levels the traversal kernels keep in LDS
-    int64_t sample_buf_cap = (int64_t)64 << 30;
-    int64_t time_kernels = 1;
-    int64_t streams = 2;  // batches in flight (1 or 2): the second stream's launches fill the first one's tails
-    // per-stream work buffers
-    struct WorkSet {
-        DevBuf path[2][4];
-        DevBuf hit, pend, shO, shD, shC, vis, shq, shO2, shD2, shq2, ctrl, spill, spill_side;
-        size_t cap_paths = 0;
-        unsigned cap_lights = 0, cap_area = 0, cap_delta = 0;
-        hipStream_t stream = nullptr;
-        hipStream_t side = nullptr;  // shadow rays + accumulate of bounce b run here beside trace of bounce b+1
-        hipEvent_t done = nullptr, ev_shade = nullptr, ev_acc = nullptr;
-    } ws[2];
-    DevBuf sample_buf, pixel_xy, tiles, tile_off, counters, stats4, hit4, scratch[8];
-    std::vector<hipEvent_t> ev_pool;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;  // hand-over between a caller's stream and the context's own
-    // every entry point that touches the context's buffers or streams holds this: calls on one
-    // context from several host threads (the reference's tile workers) are serialised
-    std::recursive_mutex mu;
-};
-
-typedef yk_context::WorkSet WorkSet;
-static const uint32_t YK_WIDE_MAX_PATHS = 6u << 20;  // jobs up to this many paths traverse the 4-wide nodes (wide_bvh = 2)
-
-struct yk_scene {
-    int device = -1;  // a scene belongs to the device, not to the context that made it: any context there renders it, and it may outlive them
-    HostBvh bvh;
-    uint32_t n_triangles = 0, n_spheres = 0, n_lights = 0, n_delta_lights = 0;
-    bool wide_auto = false;  // both node layouts on the device: the 4-wide one is used for jobs below YK_WIDE_MAX_PATHS
-    yk_scene_info info;
-    // device
-    DevBuf nodes, nodes4, top_nodes, tris, prim_shade, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights, spheres, texels, tex_info;
-    DevScene dev;
-    bool on_device = false;
-};
-
-// The device scene a job of `n` rays traverses: with both node layouts present the 4-wide one
-// serves small jobs only (see run_bounces).
-static DevScene dev_scene_for(const yk_scene* scene, uint64_t n) {
-    DevScene ds = scene->dev;
-    if (scene->wide_auto && n > YK_WIDE_MAX_PATHS) ds.nodes4 = nullptr;
-    return ds;
-}
-
-// A tile list prepared once and reused every frame (the GPU worker renders the same tiles
-// over and over): host copy + the device pixel table, so that rendering and the film update
-// need no upload and no host synchronisation.
-struct yk_tile_list {
-    int device = -1;
-    std::vector<yk_tile> tiles;
-    std::vector<uint16_t> samples;  // empty: plain film
-    std::vector<uint32_t> off;      // n_tiles + 1 pixel offsets
-    DevBuf pixel_xy, pixel_sample;
-};
-
-static yk_status fail(yk_context* ctx, yk_status st, const std::string& msg) {
-    if (ctx) ctx->last_error = msg;
-    return st;
-}
-
-#define YK_LOCK(ctx) std::lock_guard<std::recursive_mutex> yk_lock_((ctx)->mu)
-#define HIP_TRY(ctx, expr)                                                                                           \
-    do {                                                                                                             \
-        hipError_t _e = (expr);                                                                                      \
-        if (_e != hipSuccess) {                                                                                      \
-            return fail(ctx, _e == hipErrorOutOfMemory ? YK_ERR_OUT_OF_MEMORY : YK_ERR_DEVICE,                       \
-                        std::string(#expr) + ": " + hipGetErrorString(_e));                                          \
-        }                                                                                                            \
-    } while (0)
+#include "yk_internal.h"
 
 static double now_seconds() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -272,11 +164,13 @@ yk_status yk_context_set_option(yk_context* ctx, const char* key, int64_t value)
 // ------------------------------------------------------------------ host helpers
 yk_status yk_camera_init(const yk_camera_params* params, yk_camera* out) { return camera_init(params, out); }
 
-size_t yk_film_tiles(uint16_t res_x, uint16_t res_y, uint16_t tile_dim, yk_tile* out, size_t cap) {
+size_t yk_film_tiles(uint16_t res_x, uint16_t res_y, uint16_t tile_dim, yk_tile* out, size_t cap) try {
     std::vector<yk_tile> t = film_tiles(res_x, res_y, tile_dim);
     if (out)
         for (size_t i = 0; i < t.size() && i < cap; ++i) out[i] = t[i];
     return t.size();
+} catch (const std::exception&) {
+    return 0;
 }
 
 yk_status yk_make_rect_light(const float l2w[16], const float l2w_inv[16], const float radiance[3], const float size[2], yk_light_desc* out) {
@@ -421,11 +315,33 @@ static DevLight make_light(const yk_light_desc& l) {
     return d;
 }
 
-yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** out) {
-    std::unique_lock<std::recursive_mutex> yk_lock_;
-    if (ctx) yk_lock_ = std::unique_lock<std::recursive_mutex>(ctx->mu);
-    if (!d || !out) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null scene description");
-    *out = nullptr;
+}  // extern "C"
+
+// Everything yk_scene_create derives from a scene description on the host (yk_internal.h).
+struct SceneImage {
+    std::shared_ptr<const HostBvh> bvh;
+    const yk_scene_desc* d = nullptr;  // BORROWED: the caller's arrays (indices, points, normals, uvs, tri_material) are uploaded straight
+                                       // from the description, so an image is only valid inside the call that built it
+    uint32_t n_triangles = 0, n_spheres = 0, n_lights = 0, n_delta_lights = 0;
+    yk_scene_info info;  // host part: node counts, bounds, build time
+    bool has_device_records = false, wide = false, wide_auto = false;
+    uint32_t root_ref = 0;
+    std::vector<DevNode> dn, top;
+    std::vector<DevNode4> dn4;
+    std::vector<float4> tris, texels;
+    std::vector<uint4> prim_shade, tex_info;
+    std::vector<uint32_t> mesh_flags, tri_mesh;
+    std::vector<int32_t> tri_al;
+    std::vector<Material> mats;
+    std::vector<DevSphere> spheres;
+    std::vector<DevLight> lights;
+};
+
+// Host half of yk_scene_create: validation, BoundingVolumeHierarchy::new (bvh.rs:39-115) and — when `ctx` is given (its
+// "top_nodes" / "wide_bvh" options apply) — the device records laid out from the tree.
+yk_status yk_build_scene_image(yk_context* ctx, const yk_scene_desc* d, std::shared_ptr<SceneImage>& out) try {
+    if (!d) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null scene description");
+    out.reset();
     if ((uint64_t)d->n_triangles + d->n_spheres == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "empty scene");
     if (d->n_triangles && (!d->points || !d->indices)) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "missing geometry arrays");
     if (d->max_shapes_in_node == 0 || d->max_shapes_in_node > 65535u || d->split_method > 2) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "bad BVH settings");
@@ -437,6 +353,13 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
             return fail(ctx, YK_ERR_INVALID_ARGUMENT, "material index out of range");
         if (d->tri_area_light && d->tri_area_light[i] >= (int32_t)d->n_lights) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "light index out of range");
     }
+    if ((d->n_spheres && !d->spheres) || (d->n_materials && !d->materials) || (d->n_lights && !d->lights) || (d->n_meshes && !d->meshes))
+        return fail(ctx, YK_ERR_INVALID_ARGUMENT, "a count is non-zero but its array is NULL");
+    if (d->tri_area_light)  // Triangle.area_light is Option<Arc<RectangularLight>> (triangle.rs:22): -1 or a rectangular light
+        for (uint32_t i = 0; i < d->n_triangles; ++i) {
+            const int32_t al = d->tri_area_light[i];
+            if (al < -1 || (al >= 0 && d->lights[al].kind != YK_LIGHT_RECT)) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "tri_area_light must be -1 or index a rectangular light");
+        }
     for (uint32_t k = 0; k < d->n_spheres; ++k)
         if (d->spheres[k].material < 0 || (uint32_t)d->spheres[k].material >= d->n_materials) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "sphere material out of range");
     for (uint32_t m = 0; m < d->n_materials; ++m)
@@ -454,8 +377,11 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         if (d->meshes[m].has_uvs && !d->uvs) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "mesh has_uvs without a uvs array");
     }
 
-    yk_scene* s = new yk_scene();
-    s->device = ctx ? ctx->device : -1;
+    std::shared_ptr<SceneImage> img = std::make_shared<SceneImage>();
+    SceneImage* s = img.get();
+    std::shared_ptr<HostBvh> bvh = std::make_shared<HostBvh>();
+    s->bvh = bvh;
+    s->d = d;
     s->n_triangles = d->n_triangles;
     s->n_spheres = d->n_spheres;
     s->n_lights = d->n_lights;
@@ -497,7 +423,6 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         for (size_t i = 0; i < sb.size(); ++i) {
             const uint32_t src = d->shape_order[i];
             if (src >= sb.size() || seen[src]) {
-                delete s;
                 return fail(ctx, YK_ERR_INVALID_ARGUMENT, "shape_order is not a permutation of the shapes");
             }
             seen[src] = 1;
@@ -506,30 +431,27 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         sb.swap(ordered);
     }
     double t0 = now_seconds();
-    build_bvh(sb, d->max_shapes_in_node, d->split_method, s->bvh);
+    build_bvh(sb, d->max_shapes_in_node, d->split_method, *bvh);
     s->info.build_seconds = now_seconds() - t0;
     if (d->shape_order)  // leaf order -> position in Scene.shapes -> source shape
-        for (uint32_t& o : s->bvh.shape_order) o = d->shape_order[o];
-    if (s->bvh.split_failed || s->bvh.nodes.empty()) {
-        delete s;
+        for (uint32_t& o : bvh->shape_order) o = d->shape_order[o];
+    if (bvh->split_failed || bvh->nodes.empty()) {
         return fail(ctx, YK_ERR_BVH_BUILD, "BVH split failed (reference: assert_ne!(mid, start))");
     }
-    s->info.n_nodes = s->bvh.nodes.size();
-    s->info.n_shapes = s->bvh.shape_order.size();
-    s->info.max_leaf_shapes = s->bvh.max_leaf_shapes;
-    s->info.tree_depth = s->bvh.depth;
+    s->info.n_nodes = bvh->nodes.size();
+    s->info.n_shapes = bvh->shape_order.size();
+    s->info.max_leaf_shapes = bvh->max_leaf_shapes;
+    s->info.tree_depth = bvh->depth;
     for (int k = 0; k < 3; ++k) {
-        s->info.bounds_min[k] = s->bvh.nodes[0].bmin[k];
-        s->info.bounds_max[k] = s->bvh.nodes[0].bmax[k];
+        s->info.bounds_min[k] = bvh->nodes[0].bmin[k];
+        s->info.bounds_max[k] = bvh->nodes[0].bmax[k];
     }
     uint64_t n_interior = 0;
-    for (const yk_bvh_node& n : s->bvh.nodes) n_interior += n.is_leaf ? 0 : 1;
+    for (const yk_bvh_node& n : bvh->nodes) n_interior += n.is_leaf ? 0 : 1;
     s->info.n_interior = n_interior;
 
-    if (ctx) {
-        (void)hipSetDevice(ctx->device);
-        double u0 = now_seconds();
-        const std::vector<yk_bvh_node>& nodes = s->bvh.nodes;
+    if (ctx) {  // device records (a host-only scene — ctx == NULL — stops at the tree)
+        const std::vector<yk_bvh_node>& nodes = bvh->nodes;
         // interior index of each reference node = number of interior nodes before it
         std::vector<uint32_t> interior_index(nodes.size());
         uint32_t cnt = 0;
@@ -537,12 +459,12 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
             interior_index[i] = cnt;
             if (!nodes[i].is_leaf) ++cnt;
         }
-        if (nodes.size() > YK_REF_INDEX_MAX || s->bvh.shape_order.size() > YK_REF_INDEX_MAX) {
-            yk_scene_destroy(s);
+        if (nodes.size() > YK_REF_INDEX_MAX || bvh->shape_order.size() > YK_REF_INDEX_MAX) {
             return fail(ctx, YK_ERR_UNSUPPORTED, "more than 2^28 BVH nodes or shapes");
         }
         auto ref_of = [&](uint32_t idx) -> uint32_t { return nodes[idx].is_leaf ? (YK_LEAF_BIT | nodes[idx].a) : interior_index[idx]; };
-        std::vector<DevNode> dn(std::max<size_t>(n_interior, 1));
+        std::vector<DevNode>& dn = s->dn;
+        dn.assign(std::max<size_t>(n_interior, 1), DevNode());
         for (size_t i = 0; i < nodes.size(); ++i) {
             if (nodes[i].is_leaf) continue;
             const yk_bvh_node& c0 = nodes[i + 1];
@@ -554,7 +476,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
             o.q3 = make_uint4(ref_of((uint32_t)i + 1), ref_of(nodes[i].a) | ((uint32_t)nodes[i].axis << YK_AXIS_SHIFT), 0u, 0u);
         }
         // top of the tree, breadth first, for the LDS-resident copy (YK_TOP_BIT refs)
-        std::vector<DevNode> top;
+        std::vector<DevNode>& top = s->top;
         if (!nodes[0].is_leaf && ctx->top_nodes > 0) {
             std::vector<uint32_t> order;  // reference node indices, breadth first
             std::vector<uint32_t> top_id(nodes.size(), 0xffffffffu);
@@ -581,8 +503,8 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
         // 4-wide collapse (DevNode4): one node per reference interior node reached at even depth
         // below the root.  Built only while the traversal stack of the collapsed tree is
         // guaranteed to fit (the reference asserts on its own stack depth, bvh.rs:172-174).
-        std::vector<DevNode4> dn4;
-        const bool wide = ctx->wide_bvh != 0 && !nodes[0].is_leaf && s->bvh.depth <= 64;
+        std::vector<DevNode4>& dn4 = s->dn4;
+        const bool wide = s->wide = ctx->wide_bvh != 0 && !nodes[0].is_leaf && bvh->depth <= 64;
         if (wide) {
             dn4.reserve(n_interior / 2 + 1);
             struct Todo {
@@ -641,16 +563,18 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
                 o.q7 = make_uint4((uint32_t)nodes[P].axis | (axA << 2) | (axB << 4), 0u, 0u, 0u);
             }
         }
-        const size_t np = s->bvh.shape_order.size();
-        std::vector<float4> tris(3 * np);
-        std::vector<uint4> prim_shade(np);
+        const size_t np = bvh->shape_order.size();
+        std::vector<float4>& tris = s->tris;
+        tris.assign(3 * np, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        std::vector<uint4>& prim_shade = s->prim_shade;
+        prim_shade.assign(np, make_uint4(0u, 0u, 0u, 0u));
         std::vector<uint32_t> mat_kind(std::max<uint32_t>(d->n_materials, 1), 0u);  // device BSDF kind (MK_*) per material
         for (uint32_t m = 0; m < d->n_materials; ++m) mat_kind[m] = make_material(d->materials[m]).kind & 7u;
         std::vector<uint8_t> last(np, 0);
         for (const yk_bvh_node& n : nodes)
             if (n.is_leaf) last[(size_t)n.a + n.count - 1] = 1;
         for (size_t p = 0; p < np; ++p) {
-            uint32_t src = s->bvh.shape_order[p];
+            uint32_t src = bvh->shape_order[p];
             if (src >= d->n_triangles) {  // sphere: only the source index and the flags are read
                 uint32_t none = 0xffffffffu, fl = (last[p] ? YK_PRIM_LAST : 0u) | YK_PRIM_SPHERE;
                 float w0, w1, w2;
@@ -680,13 +604,16 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
             prim_shade[p] = make_uint4(d->indices[3 * src], d->indices[3 * src + 1], d->indices[3 * src + 2],
                                        ((uint32_t)d->tri_material[src] << 6) | (mat_kind[d->tri_material[src]] << 3) | mfl);
         }
-        std::vector<uint32_t> mesh_flags(std::max<uint32_t>(d->n_meshes, 1), 0);
+        std::vector<uint32_t>& mesh_flags = s->mesh_flags;
+        mesh_flags.assign(std::max<uint32_t>(d->n_meshes, 1), 0);
         for (uint32_t m = 0; m < d->n_meshes; ++m)
             mesh_flags[m] = (d->meshes[m].has_normals ? YK_MESH_NORMALS : 0u) | (d->meshes[m].has_uvs ? YK_MESH_UVS : 0u) |
                             (d->meshes[m].swaps_handedness ? YK_MESH_SWAPS : 0u);
-        std::vector<Material> mats(std::max<uint32_t>(d->n_materials, 1));
+        std::vector<Material>& mats = s->mats;
+        mats.resize(std::max<uint32_t>(d->n_materials, 1));
         for (uint32_t m = 0; m < d->n_materials; ++m) mats[m] = make_material(d->materials[m]);
-        std::vector<DevSphere> spheres(std::max<uint32_t>(d->n_spheres, 1));
+        std::vector<DevSphere>& spheres = s->spheres;
+        spheres.resize(std::max<uint32_t>(d->n_spheres, 1));
         for (uint32_t k = 0; k < d->n_spheres; ++k) {
             DevSphere& o = spheres[k];
             std::memcpy(o.o2w, d->spheres[k].object_to_world, 64);
@@ -698,61 +625,89 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
             o.swaps_handedness = det < 0.0f ? 1u : 0u;
             o.pad = 0;
         }
-        std::vector<DevLight> lights(std::max<uint32_t>(d->n_lights, 1));
+        std::vector<DevLight>& lights = s->lights;
+        lights.resize(std::max<uint32_t>(d->n_lights, 1));
         for (uint32_t l = 0; l < d->n_lights; ++l) lights[l] = make_light(d->lights[l]);
-        std::vector<uint32_t> tri_mesh(d->n_triangles, 0);
+        std::vector<uint32_t>& tri_mesh = s->tri_mesh;
+        tri_mesh.assign(d->n_triangles, 0);
         if (d->tri_mesh) std::memcpy(tri_mesh.data(), d->tri_mesh, sizeof(uint32_t) * d->n_triangles);
-        std::vector<int32_t> tri_al(d->n_triangles, -1);
+        std::vector<int32_t>& tri_al = s->tri_al;
+        tri_al.assign(d->n_triangles, -1);
         if (d->tri_area_light) std::memcpy(tri_al.data(), d->tri_area_light, sizeof(int32_t) * d->n_triangles);
 
-        yk_status st;
-#define UP(buf, ptr, n)                                   \
-    if ((st = upload(ctx, s->buf, ptr, n)) != YK_OK) {    \
-        yk_scene_destroy(s);                              \
-        return st;                                        \
+        for (uint32_t t = 0; t < d->n_textures; ++t) {
+            const yk_texture_desc& td = d->textures[t];
+            s->tex_info.push_back(make_uint4((unsigned)s->texels.size(), td.width, td.height, 0u));
+            const size_t n = (size_t)td.width * td.height;
+            if (s->texels.size() + n > 0xffffffffull) return fail(ctx, YK_ERR_UNSUPPORTED, "more than 2^32 texels");
+            for (size_t k = 0; k < n; ++k) s->texels.push_back(make_float4(td.rgb[3 * k], td.rgb[3 * k + 1], td.rgb[3 * k + 2], 0.0f));
+        }
+        s->root_ref = ref_of(0);
+        s->wide_auto = wide && ctx->wide_bvh == 2;
+        s->has_device_records = true;
     }
-        UP(nodes, dn.data(), dn.size());
-        UP(nodes4, dn4.data(), dn4.size());
-        UP(top_nodes, top.data(), top.size());
-        UP(tris, tris.data(), tris.size());
-        UP(prim_shade, prim_shade.data(), prim_shade.size());
+    out = img;
+    return YK_OK;
+} YK_CATCH(ctx)
+
+// Device half: one copy of the image in the HBM of ctx's device.
+yk_status yk_upload_scene_image(yk_context* ctx, const std::shared_ptr<SceneImage>& img, yk_scene** out) try {
+    if (!out) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null out");
+    *out = nullptr;
+    if (!img || !img->bvh) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null scene image");
+    yk_scene* s = new yk_scene();
+    struct SceneGuard {  // frees the half-built scene on every early return and on an exception
+        yk_scene* s;
+        ~SceneGuard() {
+            if (s) yk_scene_destroy(s);
+        }
+    } guard{s};
+    s->device = ctx ? ctx->device : -1;
+    s->bvh = img->bvh;
+    s->n_triangles = img->n_triangles;
+    s->n_spheres = img->n_spheres;
+    s->n_lights = img->n_lights;
+    s->n_delta_lights = img->n_delta_lights;
+    s->info = img->info;
+    if (ctx) {
+        if (!img->has_device_records) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "scene image was built without device records");
+        const yk_scene_desc* d = img->d;
+        (void)hipSetDevice(ctx->device);
+        double u0 = now_seconds();
+        yk_status st;
+#define UP(buf, ptr, n) \
+    if ((st = upload(ctx, s->buf, ptr, n)) != YK_OK) return st;
+        UP(nodes, img->dn.data(), img->dn.size());
+        UP(nodes4, img->dn4.data(), img->dn4.size());
+        UP(top_nodes, img->top.data(), img->top.size());
+        UP(tris, img->tris.data(), img->tris.size());
+        UP(prim_shade, img->prim_shade.data(), img->prim_shade.size());
         UP(indices, d->indices, 3 * (size_t)d->n_triangles);
         UP(points, d->points, 3 * (size_t)d->n_vertices);
         UP(normals, d->normals, d->normals ? 3 * (size_t)d->n_vertices : 0);
         UP(uvs, d->uvs, d->uvs ? 2 * (size_t)d->n_vertices : 0);
-        UP(tri_mesh, tri_mesh.data(), tri_mesh.size());
+        UP(tri_mesh, img->tri_mesh.data(), img->tri_mesh.size());
         UP(tri_material, d->tri_material, (size_t)d->n_triangles);
-        UP(tri_area_light, tri_al.data(), tri_al.size());
-        UP(mesh_flags, mesh_flags.data(), mesh_flags.size());
-        UP(materials, mats.data(), mats.size());
-        UP(lights, lights.data(), lights.size());
-        UP(spheres, spheres.data(), spheres.size());
-        std::vector<uint4> tex_info;
-        std::vector<float4> texels;
-        for (uint32_t t = 0; t < d->n_textures; ++t) {
-            const yk_texture_desc& td = d->textures[t];
-            tex_info.push_back(make_uint4((unsigned)texels.size(), td.width, td.height, 0u));
-            const size_t n = (size_t)td.width * td.height;
-            if (texels.size() + n > 0xffffffffull) {
-                yk_scene_destroy(s);
-                return fail(ctx, YK_ERR_UNSUPPORTED, "more than 2^32 texels");
-            }
-            for (size_t k = 0; k < n; ++k) texels.push_back(make_float4(td.rgb[3 * k], td.rgb[3 * k + 1], td.rgb[3 * k + 2], 0.0f));
-        }
-        UP(texels, texels.data(), texels.size());
-        UP(tex_info, tex_info.data(), tex_info.size());
+        UP(tri_area_light, img->tri_al.data(), img->tri_al.size());
+        UP(mesh_flags, img->mesh_flags.data(), img->mesh_flags.size());
+        UP(materials, img->mats.data(), img->mats.size());
+        UP(lights, img->lights.data(), img->lights.size());
+        UP(spheres, img->spheres.data(), img->spheres.size());
+        UP(texels, img->texels.data(), img->texels.size());
+        UP(tex_info, img->tex_info.data(), img->tex_info.size());
 #undef UP
+        const std::vector<yk_bvh_node>& nodes = img->bvh->nodes;
         DevScene& ds = s->dev;
         ds.nodes = s->nodes.as<DevNode>();
-        ds.nodes4 = wide ? s->nodes4.as<DevNode4>() : nullptr;
-        s->wide_auto = wide && ctx->wide_bvh == 2;
+        ds.nodes4 = img->wide ? s->nodes4.as<DevNode4>() : nullptr;
+        s->wide_auto = img->wide_auto;
         ds.top_nodes = s->top_nodes.as<DevNode>();
-        ds.n_top = (uint32_t)top.size();
+        ds.n_top = (uint32_t)img->top.size();
         ds.tris = s->tris.as<float4>();
         ds.prim_shade = s->prim_shade.as<uint4>();
         ds.spheres = d->n_spheres ? s->spheres.as<DevSphere>() : nullptr;
         ds.n_triangles = d->n_triangles;
-        ds.root_ref = ref_of(0);
+        ds.root_ref = img->root_ref;
         for (int k = 0; k < 3; ++k) {
             ds.root_bmin[k] = nodes[0].bmin[k];
             ds.root_bmax[k] = nodes[0].bmax[k];
@@ -777,9 +732,24 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
                          &s->mesh_flags, &s->materials, &s->lights, &s->spheres, &s->texels, &s->tex_info};
         for (DevBuf* b : all) s->info.device_bytes += b->bytes;
     }
+    guard.s = nullptr;
     *out = s;
     return YK_OK;
+} YK_CATCH(ctx)
+
+extern "C" {
+
+yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** out) {
+    std::unique_lock<std::recursive_mutex> yk_lock_;
+    if (ctx) yk_lock_ = std::unique_lock<std::recursive_mutex>(ctx->mu);
+    if (!d || !out) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null scene description");
+    *out = nullptr;
+    std::shared_ptr<SceneImage> img;
+    yk_status st = yk_build_scene_image(ctx, d, img);
+    if (st != YK_OK) return st;
+    return yk_upload_scene_image(ctx, img, out);
 }
+
 
 void yk_scene_destroy(yk_scene* s) {
     if (!s) return;
@@ -798,13 +768,20 @@ yk_status yk_scene_get_info(const yk_scene* s, yk_scene_info* out) {
 
 yk_status yk_scene_export_bvh(const yk_scene* s, yk_bvh_node* nodes, uint32_t* shape_order) {
     if (!s) return YK_ERR_INVALID_ARGUMENT;
-    if (nodes) std::memcpy(nodes, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(yk_bvh_node));
-    if (shape_order) std::memcpy(shape_order, s->bvh.shape_order.data(), s->bvh.shape_order.size() * sizeof(uint32_t));
+    if (nodes) std::memcpy(nodes, s->bvh->nodes.data(), s->bvh->nodes.size() * sizeof(yk_bvh_node));
+    if (shape_order) std::memcpy(shape_order, s->bvh->shape_order.data(), s->bvh->shape_order.size() * sizeof(uint32_t));
     return YK_OK;
 }
 
 // ------------------------------------------------------------------ render
+// ctx->counters: 8 x u64 (closest-hit rays, shadow rays, ...) followed by a 4-word error block whose word
+// YK_CTRL_ERR the traversal kernels set on a stack overflow.  Both are zeroed ONCE per call (begin_call) — the
+// per-batch control blocks of the work sets are zeroed with every batch and must not hold the flag.
+#define YK_COUNTER_BYTES 96
+static unsigned* error_block(yk_context* ctx) { return reinterpret_cast<unsigned*>(ctx->counters.as<unsigned long long>() + 8); }
+
 static yk_status ensure_work_buffers(yk_context* ctx, WorkSet& ws, size_t paths, unsigned n_lights, unsigned n_delta_lights) {
+    HIP_TRY(ctx, ctx->counters.ensure(YK_COUNTER_BYTES));
     unsigned nl = std::max(1u, n_lights);
     unsigned na = nl, nd = std::max(1u, n_delta_lights);  // queue 1 holds every light's rays on the bounces that are not split
     if (paths <= ws.cap_paths && nl <= ws.cap_lights && na <= ws.cap_area && nd <= ws.cap_delta) return YK_OK;
@@ -826,7 +803,6 @@ static yk_status ensure_work_buffers(yk_context* ctx, WorkSet& ws, size_t paths,
     HIP_TRY(ctx, ws.shD2.ensure(paths * nd * 16));
     HIP_TRY(ctx, ws.shq2.ensure(paths * nd * 4));
     HIP_TRY(ctx, ws.ctrl.ensure(YK_CTRL_WORDS * 4));
-    HIP_TRY(ctx, ctx->counters.ensure(64));
     ws.cap_paths = paths;
     ws.cap_lights = nl;
     ws.cap_area = na;
@@ -912,6 +888,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
                         const uint32_t* sample_index_tab, float4* sample_buf, KernelTimer& kt, unsigned long long* counters, bool coherent,
                         uint32_t n_paths, uint32_t* n_shadow_launches = nullptr) {
     unsigned* ctrl = ws.ctrl.as<unsigned>();
+    unsigned* errblk = error_block(ctx);  // outlives the batch (ctrl is zeroed per batch)
     // Two node layouts: the binary 64-byte nodes win when the machine is full (one 4-wide node
     // costs the loads of two binary ones, and throughput is bound by per-lane loads);
     // the 4-wide collapse halves the dependent steps of a ray, which is what a job too small to
@@ -946,8 +923,8 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         PathBuffers pc = path_buffers(ws, (int)cur), pn = path_buffers(ws, (int)(cur ^ 1u));
         // camera rays (consecutive samples of a pixel) and the shadow rays they spawn are coherent:
         // the wave walks the tree once for all 64 of them (yk_packet.hip)
-        const bool packet = coherent && b < (unsigned)ctx->packet_bounces && scene->bvh.depth <= 64;
-        const bool packet_shadow = coherent && b < (unsigned)ctx->packet_shadow_bounces && scene->bvh.depth <= 64 && scene->n_delta_lights > 0;
+        const bool packet = coherent && b < (unsigned)ctx->packet_bounces && scene->bvh->depth <= 64;
+        const bool packet_shadow = coherent && b < (unsigned)ctx->packet_shadow_bounces && scene->bvh->depth <= 64 && scene->n_delta_lights > 0;
         // shadow rays are split into two queues only when the second one gets the packet kernel;
         // otherwise everything goes to the first queue and one launch traces it
         const bool split = packet_shadow && scene->n_lights > scene->n_delta_lights;
@@ -958,7 +935,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
             launch_trace_closest_packet(st, pg, ds, pc.rayO, pc.rayD, bc, bc + YK_CTRL_HEAD, ws.hit.as<int>(), counters);
         else
             launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, bc, bc + YK_CTRL_HEAD, ws.hit.as<int>(), nullptr, nullptr,
-                                 ws.spill.as<uint2>(), spill_stride, ctrl, counters);
+                                 ws.spill.as<uint2>(), spill_stride, errblk, counters);
         kt.end(e, 0, st);
         if (overlap && b > 0) (void)hipStreamWaitEvent(st, ws.ev_acc, 0);
         e = kt.begin(st);
@@ -977,7 +954,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
                                     bc + YK_CTRL_HEAD + 1, ws.vis.as<unsigned char>(), counters + 1);
         } else {
             launch_trace_any(sb, tg_any, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), bc + YK_CTRL_SHQ,
-                             bc + YK_CTRL_HEAD + 1, ws.vis.as<unsigned char>(), any_spill, spill_stride, ctrl, counters + 1);
+                             bc + YK_CTRL_HEAD + 1, ws.vis.as<unsigned char>(), any_spill, spill_stride, errblk, counters + 1);
             if (split && n_shadow_launches) ++*n_shadow_launches;
             if (split)  // rays converging on a point / spot / distant light: wave packets
                 launch_trace_any_packet(sb, pg_any, ds, ws.shO2.as<float4>(), ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc + YK_CTRL_SHQ2,
@@ -1012,7 +989,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
 static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
                                    const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
                                    void* d_out_rgb, void* stream, yk_render_stats* stats, yk_cancel_fn cancel, void* user,
-                                   const yk_tile_list* prepared = nullptr, uint32_t n_passes = 1) {
+                                   const yk_tile_list* prepared = nullptr, uint32_t n_passes = 1) try {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (prepared) {
@@ -1108,7 +1085,8 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
     if (!is_path && prm.integrator == YK_INTEGRATOR_BVH_INTERSECTIONS) HIP_TRY(ctx, ctx->stats4.ensure(batch * 16));
 
     unsigned long long* counters = ctx->counters.as<unsigned long long>();
-    HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64, st));
+    HIP_TRY(ctx, hipMemsetAsync(counters, 0, YK_COUNTER_BYTES, st));
+    unsigned* errblk = error_block(ctx);
     KernelTimer kt;
     kt.ctx = ctx;
     // per-kernel HIP-event timings: two event records per launch and one elapsed-time query per
@@ -1190,7 +1168,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
                 // one lane per camera sample runs the whole recursion (whitted.rs:74-181)
                 int e = kt.begin(bs);
                 launch_whitted(bs, trace_grid(ctx), scene->dev, prm, pixel_xy, pixel_sample, path_buffers(ws, 0), n, sample_buf, ws.spill.as<uint2>(),
-                               trace_grid(ctx) * trace_block_size(), ctrl, counters);
+                               trace_grid(ctx) * trace_block_size(), errblk, counters);
                 kt.end(e, 0, bs);
                 ++n_trace;
             } else {
@@ -1198,7 +1176,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
                 const bool want_stats = prm.integrator == YK_INTEGRATOR_BVH_INTERSECTIONS;
                 int e = kt.begin(bs);
                 launch_trace_closest(bs, trace_grid(ctx), dev_scene_for(scene, n), pc.rayO, pc.rayD, nullptr, ctrl + YK_CTRL_BOUNCE(0), ctrl + YK_CTRL_BOUNCE(0) + YK_CTRL_HEAD, ws.hit.as<int>(), nullptr,
-                                     want_stats ? ctx->stats4.as<uint4>() : nullptr, ws.spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), ctrl,
+                                     want_stats ? ctx->stats4.as<uint4>() : nullptr, ws.spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), errblk,
                                      counters);
                 kt.end(e, 0, bs);
                 launch_debug_shade(bs, scene->dev, prm.integrator, pc, ws.hit.as<int>(), ctx->stats4.as<uint4>(), n, sample_buf);
@@ -1221,15 +1199,10 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         HIP_TRY(ctx, hipEventRecord(ev1, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         std::memset(stats, 0, sizeof(*stats));
-        unsigned long long host_counters[8];
-        unsigned host_ctrl[4];
-        HIP_TRY(ctx, hipMemcpy(host_counters, counters, 64, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(host_ctrl, ctx->ws[0].ctrl.p, 16, hipMemcpyDeviceToHost));
-        if (n_ws == 2) {
-            unsigned c1[4];
-            HIP_TRY(ctx, hipMemcpy(c1, ctx->ws[1].ctrl.p, 16, hipMemcpyDeviceToHost));
-            host_ctrl[YK_CTRL_ERR] |= c1[YK_CTRL_ERR];
-        }
+        unsigned long long host_counters[YK_COUNTER_BYTES / 8];
+        HIP_TRY(ctx, hipMemcpy(host_counters, counters, YK_COUNTER_BYTES, hipMemcpyDeviceToHost));
+        unsigned host_err[4];
+        std::memcpy(host_err, host_counters + 8, sizeof(host_err));
         float ms = 0.0f;
         (void)hipEventElapsedTime(&ms, ev0, ev1);
         stats->rays = host_counters[0];
@@ -1242,10 +1215,17 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         stats->trace_launches = n_trace;
         stats->shadow_launches = n_shadow;
         stats->batches = n_batches;
-        if (host_ctrl[YK_CTRL_ERR] & 1u) return fail(ctx, YK_ERR_STACK_OVERFLOW, "BVH traversal stack exceeded 64 entries (bvh.rs:174)");
+        if (host_err[YK_CTRL_ERR] & 1u) return fail(ctx, YK_ERR_STACK_OVERFLOW, "BVH traversal stack exceeded 64 entries (bvh.rs:174)");
+    } else if (scene->bvh->depth > 64) {
+        // A tree deeper than the reference's 64-entry stack (bvh.rs:172-174) can overflow it: such a render is
+        // not left asynchronous — the flag is read before the call returns, whoever the caller is.
+        unsigned host_err[4];
+        HIP_TRY(ctx, hipMemcpyAsync(host_err, errblk, sizeof(host_err), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (host_err[YK_CTRL_ERR] & 1u) return fail(ctx, YK_ERR_STACK_OVERFLOW, "BVH traversal stack exceeded 64 entries (bvh.rs:174)");
     }
     return YK_OK;
-}
+} YK_CATCH(ctx)
 
 static yk_status render_tiles_host(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
                                    const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
@@ -1286,7 +1266,7 @@ yk_status yk_render_tiles_accumulating_passes(yk_context* ctx, const yk_scene* s
     return render_tiles_host(ctx, scene, camera, sampler, integrator, tiles, tile_samples, n_tiles, out_rgb, stats, cancel, user, n_passes);
 }
 
-yk_status yk_tile_list_create(yk_context* ctx, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles, yk_tile_list** out) {
+yk_status yk_tile_list_create(yk_context* ctx, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles, yk_tile_list** out) try {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (!tiles || !out || n_tiles == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
@@ -1341,7 +1321,7 @@ yk_status yk_tile_list_create(yk_context* ctx, const yk_tile* tiles, const uint1
     }
     *out = l;
     return YK_OK;
-}
+} YK_CATCH(ctx)
 
 void yk_tile_list_destroy(yk_tile_list* l) {
     if (!l) return;
@@ -1460,7 +1440,7 @@ yk_status yk_film_accumulate_tiles_device(yk_context* ctx, const yk_tile* tiles,
 }  // extern "C"
 
 static yk_status film_tiles_device(yk_context* ctx, const yk_tile* tiles, size_t n_tiles, const void* d_tile_rgb, uint16_t res_x, uint16_t res_y,
-                                   void* d_film_rgb, void* stream, int accumulate) {
+                                   void* d_film_rgb, void* stream, int accumulate) try {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (!tiles || !d_tile_rgb || !d_film_rgb || n_tiles == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
@@ -1487,13 +1467,13 @@ static yk_status film_tiles_device(yk_context* ctx, const yk_tile* tiles, size_t
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return YK_OK;
-}
+} YK_CATCH(ctx)
 
 extern "C" {
 
 yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* sampler, const yk_integrator_desc* integrator, size_t n,
                 const float* ray_o, const float* ray_d, const uint16_t* pixel_xy, const uint32_t* sample_index, uint32_t dimension, float* out_li,
-                uint32_t* out_ray_counts) {
+                uint32_t* out_ray_counts) try {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (!scene || !ray_o || !ray_d || !pixel_xy || !sample_index || !out_li || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
@@ -1525,7 +1505,7 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
     HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[7].p, sample_index, n * 4, hipMemcpyHostToDevice, st));
     unsigned* ctrl = ctx->ws[0].ctrl.as<unsigned>();
     unsigned long long* counters = ctx->counters.as<unsigned long long>();
-    HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64, st));
+    HIP_TRY(ctx, hipMemsetAsync(counters, 0, YK_COUNTER_BYTES, st));
     HIP_TRY(ctx, hipMemsetAsync(ctrl, 0, YK_CTRL_WORDS * 4, st));
     launch_raygen_user(st, prm, ctx->scratch[4].as<float>(), ctx->scratch[5].as<float>(), ctx->scratch[6].as<uint16_t>(), ctx->scratch[7].as<uint32_t>(),
                        dimension, (uint32_t)n, path_buffers(ctx->ws[0], 0), ctx->sample_buf.as<float4>(), ctx->pixel_xy.as<uint32_t>(), ctrl + YK_CTRL_BOUNCE(0));
@@ -1534,13 +1514,16 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
     kt.on = false;
     if (prm.integrator == YK_INTEGRATOR_WHITTED)
         launch_whitted(st, trace_grid(ctx), scene->dev, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), path_buffers(ctx->ws[0], 0), (uint32_t)n,
-                       ctx->sample_buf.as<float4>(), ctx->ws[0].spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), ctrl, counters);
+                       ctx->sample_buf.as<float4>(), ctx->ws[0].spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), error_block(ctx), counters);
     else
         run_bounces(ctx, ctx->ws[0], st, scene, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), ctx->sample_buf.as<float4>(), kt, counters, false, (uint32_t)n);
     HIP_TRY(ctx, hipGetLastError());
     std::vector<float> tmp(n * 4);
+    unsigned host_err[4];
     HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->sample_buf.p, n * 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(host_err, error_block(ctx), sizeof(host_err), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (host_err[YK_CTRL_ERR] & 1u) return fail(ctx, YK_ERR_STACK_OVERFLOW, "BVH traversal stack exceeded 64 entries (bvh.rs:174)");
     for (size_t i = 0; i < n; ++i) {
         out_li[3 * i] = tmp[4 * i];
         out_li[3 * i + 1] = tmp[4 * i + 1];
@@ -1548,12 +1531,12 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
     }
     if (out_ray_counts) std::memset(out_ray_counts, 0, n * 4);  // per-ray counts are not tracked by the wavefront
     return YK_OK;
-}
+} YK_CATCH(ctx)
 
 // ------------------------------------------------------------------ per-stage entry points
 yk_status yk_trace_closest(yk_context* ctx, const yk_scene* scene, size_t n, const float* ray_o, const float* ray_d, const float* t_max,
                            int32_t* out_shape, float* out_t, float* out_bary, uint32_t* out_node_tests, uint32_t* out_node_hits,
-                           uint32_t* out_shape_tests) {
+                           uint32_t* out_shape_tests) try {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (!scene || !ray_o || !ray_d || !out_shape || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
@@ -1611,7 +1594,7 @@ yk_status yk_trace_closest(yk_context* ctx, const yk_scene* scene, size_t n, con
     }
     if (host_ctrl[YK_CTRL_ERR] & 1u) return fail(ctx, YK_ERR_STACK_OVERFLOW, "BVH traversal stack exceeded 64 entries (bvh.rs:174)");
     return YK_OK;
-}
+} YK_CATCH(ctx)
 
 yk_status yk_trace_any(yk_context* ctx, const yk_scene* scene, size_t n, const float* ray_o, const float* ray_d, const float* t_max,
                        const int32_t* area_light, uint8_t* out_hit) {
@@ -1644,7 +1627,10 @@ yk_status yk_trace_any(yk_context* ctx, const yk_scene* scene, size_t n, const f
                      ctx->ws[0].vis.as<unsigned char>(), ctx->ws[0].spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), ctrl, nullptr);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(out_hit, ctx->ws[0].vis.p, n, hipMemcpyDeviceToHost, st));
+    unsigned host_ctrl[4];
+    HIP_TRY(ctx, hipMemcpyAsync(host_ctrl, ctrl, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (host_ctrl[YK_CTRL_ERR] & 1u) return fail(ctx, YK_ERR_STACK_OVERFLOW, "BVH traversal stack exceeded 64 entries (bvh.rs:174)");
     return YK_OK;
 }
 
@@ -1670,7 +1656,7 @@ yk_status yk_sampler_sequence(yk_context* ctx, const yk_sampler_desc* sampler, u
 }
 
 yk_status yk_camera_rays(yk_context* ctx, const yk_camera* camera, const yk_sampler_desc* sampler, const yk_tile* tile, uint32_t sample_index,
-                         float* out_o, float* out_d) {
+                         float* out_o, float* out_d) try {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (!camera || !sampler || !tile || !out_o || !out_d) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
@@ -1714,7 +1700,7 @@ yk_status yk_camera_rays(yk_context* ctx, const yk_camera* camera, const yk_samp
             out_d[3 * p + k] = d[3 * ((size_t)p * spp + sample_index) + k];
         }
     return YK_OK;
-}
+} YK_CATCH(ctx)
 
 yk_status yk_device_math(yk_context* ctx, int fn, size_t n, const float* a, const float* b, float* out) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;

@@ -1,0 +1,134 @@
+// yk_internal.h — library-private definitions shared by yk_api.cpp (single-device entry points) and
+// yk_multi.cpp (several devices of one process, RCCL): the objects behind the opaque handles of
+// include/yuki_hip.h.  Not installed.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "yk_device.h"
+#include "yk_host.h"
+#include "yk_kernels.h"
+
+using namespace yk;
+
+// ------------------------------------------------------------------ helpers
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t want) {
+        if (want <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct yk_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    int n_cu = 256;
+    // options
+    int64_t batch_paths = 128 << 20;
+    int64_t packet_bounces = 1;         // leading bounces whose closest-hit rays use the wave-packet kernel (camera rays are coherent); 0 = never
+    int64_t packet_shadow_bounces = 1;  // same for the shadow rays towards point / spot / distant lights (their own queue)
+    int64_t shade_reorder = 1;   // deal the paths of a shade block to its lanes sorted by material kind (bounces > 0)
+    int64_t overlap_shadow = 1;  // run {trace_any, accumulate}(b) on a side stream beside trace_closest(b+1)
+    int64_t wide_bvh = 2;   // scenes created afterwards: 0 binary nodes only, 1 traverse the 4-wide collapse, 2 keep both and pick per job
+    int64_t top_nodes = YK_TOP_MAX; // interior nodes (capped by what the kernels were built for) of the first tree levels the traversal kernels keep in LDS
+    int64_t sample_buf_cap = (int64_t)64 << 30;
+    int64_t time_kernels = 1;
+    int64_t streams = 2;  // batches in flight (1 or 2): the second stream's launches fill the first one's tails
+    // per-stream work buffers
+    struct WorkSet {
+        DevBuf path[2][4];
+        DevBuf hit, pend, shO, shD, shC, vis, shq, shO2, shD2, shq2, ctrl, spill, spill_side;
+        size_t cap_paths = 0;
+        unsigned cap_lights = 0, cap_area = 0, cap_delta = 0;
+        hipStream_t stream = nullptr;
+        hipStream_t side = nullptr;  // shadow rays + accumulate of bounce b run here beside trace of bounce b+1
+        hipEvent_t done = nullptr, ev_shade = nullptr, ev_acc = nullptr;
+    } ws[2];
+    DevBuf sample_buf, pixel_xy, tiles, tile_off, counters, stats4, hit4, scratch[8];
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;  // hand-over between a caller's stream and the context's own
+    // every entry point that touches the context's buffers or streams holds this: calls on one
+    // context from several host threads (the reference's tile workers) are serialised
+    std::recursive_mutex mu;
+};
+
+typedef yk_context::WorkSet WorkSet;
+static const uint32_t YK_WIDE_MAX_PATHS = 6u << 20;  // jobs up to this many paths traverse the 4-wide nodes (wide_bvh = 2)
+
+struct yk_scene {
+    int device = -1;  // a scene belongs to the device, not to the context that made it: any context there renders it, and it may outlive them
+    std::shared_ptr<const HostBvh> bvh;  // one host tree may serve the copies of a scene on several devices (yk_multi_scene)
+    uint32_t n_triangles = 0, n_spheres = 0, n_lights = 0, n_delta_lights = 0;
+    bool wide_auto = false;  // both node layouts on the device: the 4-wide one is used for jobs below YK_WIDE_MAX_PATHS
+    yk_scene_info info;
+    // device
+    DevBuf nodes, nodes4, top_nodes, tris, prim_shade, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights, spheres, texels, tex_info;
+    DevScene dev;
+    bool on_device = false;
+};
+
+// The device scene a job of `n` rays traverses: with both node layouts present the 4-wide one
+// serves small jobs only (see run_bounces).
+static inline DevScene dev_scene_for(const yk_scene* scene, uint64_t n) {
+    DevScene ds = scene->dev;
+    if (scene->wide_auto && n > YK_WIDE_MAX_PATHS) ds.nodes4 = nullptr;
+    return ds;
+}
+
+// A tile list prepared once and reused every frame (the GPU worker renders the same tiles
+// over and over): host copy + the device pixel table, so that rendering and the film update
+// need no upload and no host synchronisation.
+struct yk_tile_list {
+    int device = -1;
+    std::vector<yk_tile> tiles;
+    std::vector<uint16_t> samples;  // empty: plain film
+    std::vector<uint32_t> off;      // n_tiles + 1 pixel offsets
+    DevBuf pixel_xy, pixel_sample;
+};
+
+static inline yk_status fail(yk_context* ctx, yk_status st, const std::string& msg) {
+    if (ctx) ctx->last_error = msg;
+    return st;
+}
+
+#define YK_LOCK(ctx) std::lock_guard<std::recursive_mutex> yk_lock_((ctx)->mu)
+#define HIP_TRY(ctx, expr)                                                                                           \
+    do {                                                                                                             \
+        hipError_t _e = (expr);                                                                                      \
+        if (_e != hipSuccess) {                                                                                      \
+            return fail(ctx, _e == hipErrorOutOfMemory ? YK_ERR_OUT_OF_MEMORY : YK_ERR_DEVICE,                       \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                                          \
+        }                                                                                                            \
+    } while (0)
+
+// No exception crosses the C ABI (undefined behaviour for a Rust caller, an abort under ctypes): entry points that
+// allocate host memory are function-try-blocks ending in this handler.
+#define YK_CATCH(ctx)                                                                                         \
+    catch (const std::bad_alloc&) { return fail(ctx, YK_ERR_OUT_OF_MEMORY, "host allocation failed"); }      \
+    catch (const std::exception& e) { return fail(ctx, YK_ERR_INVALID_ARGUMENT, std::string("exception: ") + e.what()); }
+
+
+// Everything yk_scene_create derives from a scene description on the host — the reference's BVH
+// (BoundingVolumeHierarchy::new, bvh.rs:39-115) and the device records laid out from it.  Built once;
+// uploaded to one device (yk_scene_create) or to every device of a yk_multi (yk_multi_scene_create).
+struct SceneImage;
+yk_status yk_build_scene_image(yk_context* opt_ctx, const yk_scene_desc* d, std::shared_ptr<SceneImage>& out);
+yk_status yk_upload_scene_image(yk_context* ctx, const std::shared_ptr<SceneImage>& img, yk_scene** out);

@@ -344,6 +344,29 @@ def coplanar_slabs(seed=7):
         camera=dict(position=(2.3, -0.1, -1.3), target=(0.0, 0.0, 0.0), up=(0, 1, 0), fov_axis=abi.FOV_Y, fov_degrees=70.0), name="coplanar-slabs")
 
 
+def deep_chain(n=70):
+    """A BVH as deep as it has shapes: n large triangles in the planes x = 3^-k.  The Middle
+    split (bvh.rs:341-372) cuts the centroid range in half, which separates the one triangle
+    with the largest x from all the others, level after level.  A ray travelling towards +x
+    enters the nested child first and defers the single-triangle child every time, so its
+    traversal stack holds n - 1 entries before the first leaf is visited: n > 65 exceeds the
+    reference's 64-entry stack (assert at bvh.rs:174)."""
+    xs = (F(3.0) ** -np.arange(n, dtype=np.float64)).astype(F)
+    pts = np.zeros((3 * n, 3), dtype=F)
+    for k in range(n):
+        pts[3 * k] = (xs[k], -2.0, -2.0)
+        pts[3 * k + 1] = (xs[k], 2.0, -2.0)
+        pts[3 * k + 2] = (xs[k], 0.0, 2.0)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    l2w, _ = _translation((-1.0, 0.5, 0.0))
+    return SceneData(
+        points=pts, indices=idx, tri_mesh=np.zeros(n, dtype=np.uint32), tri_material=(np.arange(n) % 2).astype(np.int32),
+        tri_area_light=np.full(n, -1, dtype=np.int32), meshes=[(False, False, False)],
+        materials=[dict(kind=abi.MAT_MATTE, a=(0.7, 0.6, 0.5), c=0.0), dict(kind=abi.MAT_GLASS, a=(1.0, 1.0, 1.0), b=(1.0, 1.0, 1.0), c=1.5)],
+        lights=[dict(kind="point", l2w=l2w, I=(4.0, 4.0, 4.0))], background=(0.2, 0.2, 0.2), split_method=abi.SPLIT_MIDDLE, max_shapes_in_node=1,
+        camera=dict(position=(-1.0, 0.0, 0.0), target=(1.0, 0.0, 0.0), up=(0, 1, 0), fov_axis=abi.FOV_X, fov_degrees=20.0), name=f"deep-chain-{n}")
+
+
 # --------------------------------------------------------------------------- cfg 2: bunny-class mesh
 def _cube_sphere(n):
     """6 faces x n x n quads; returns unit-sphere points (nv,3) f64 and triangles (nt,3)."""
@@ -577,6 +600,8 @@ def by_name(name):
         return glass_balls()
     if name == "coplanar-slabs":
         return coplanar_slabs()
+    if name.startswith("deep-chain-"):
+        return deep_chain(int(name.split("-")[-1]))
     if name == "cfg2":
         return bunny_class()
     if name == "cfg3":
