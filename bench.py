@@ -438,11 +438,15 @@ def main():
             ceil_l1 = gather_ceiling(0)
             ceil_tab = gather_ceiling(table_bytes)
 
-            def family(name, key, kernels, seconds, n_launch, units, alg_bytes):
+            def family(name, key, kernels, seconds, n_launch, units, alg_bytes, stream_bytes_per_unit):
                 avg_s = seconds / max(1, n_launch)
                 fam = pmc_d.get(key, {})
-                traffic = fam.get("hbm_bytes_per_launch")
-                d = dict(bound="hbm", what="L2-miss (fabric-side) traffic incl. Infinity-Cache hits: PMC FETCH_SIZE x 2 + WRITE_SIZE per launch / live launch duration",
+                traffic = None
+                if fam.get("fetch_size_bytes_per_launch") is not None:
+                    # FETCH_SIZE counts per-lane gathers (nodes, triangles) at full size and coalesced 16-B-per-lane streams (the ray
+                    # records) at half (calibration: profiles/*_gather_bench.json): add the missing half of the streamed bytes
+                    traffic = fam["fetch_size_bytes_per_launch"] + 0.5 * stream_bytes_per_unit * units / max(1, n_launch) + fam.get("write_size_bytes_per_launch", 0.0)
+                d = dict(bound="hbm", what="L2-miss (fabric-side) traffic incl. Infinity-Cache hits: PMC FETCH_SIZE (gathers at full size, + the uncounted half of the streamed ray records) + WRITE_SIZE per launch / live launch duration",
                          kernel=name, kernels=kernels, achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None, traffic=traffic, traffic_source=pmc_src,
                          avg_launch_ms=avg_s * 1e3, launches=n_launch, rays_per_launch=units / max(1, n_launch),
                          timing="one untimed probe step with overlap_shadow=0: every launch alone on the GPU, HIP events on its stream")
@@ -457,9 +461,19 @@ def main():
                 # family against the rate the gather micro-benchmark reaches with an L1-resident table (same counter, same pass).
                 acc = fam.get("tcp_accesses_per_launch")
                 if acc and ceil_l1 and ceil_l1.get("tcp_accesses_per_s"):
-                    rate = acc / avg_s
-                    d["vector_memory"] = dict(achieved=rate * 1e-9, peak=ceil_l1["tcp_accesses_per_s"] * 1e-9, unit="G L1 accesses/s", frac=rate / ceil_l1["tcp_accesses_per_s"],
-                                              source=ceil_l1["source"])
+                    # TCP_TOTAL_ACCESSES counts 64 per vector-memory wave-instruction whatever the EXEC mask, while the gather loop's cost
+                    # follows the ACTIVE lanes (masked modes 3-6 of the micro-benchmark): scale by the kernels' VALU lane utilisation
+                    util = fam.get("valu_lane_utilisation", 1.0)
+                    rate = acc * util / avg_s
+                    d["vector_memory"] = dict(achieved=rate * 1e-9, peak=ceil_l1["tcp_accesses_per_s"] * 1e-9, unit="G active-lane L1 accesses/s", frac=rate / ceil_l1["tcp_accesses_per_s"],
+                                              lane_utilisation=util, source=ceil_l1["source"],
+                                              note="estimate: TCP_TOTAL_ACCESSES x VALU lane utilisation (a proxy for the EXEC mask of the loads) against the rate of the gather micro-benchmark (table <= L2)")
+                # TA (the CU's vector-memory address unit) busy cycles, summed over the 256 CUs, against the launch's shader-clock
+                # cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs): how much of the time the vector-memory path is occupied
+                if fam.get("ta_busy_cycles_per_launch") and fam.get("grbm_gui_active_per_launch"):
+                    d["ta_busy"] = dict(achieved=fam["ta_busy_cycles_per_launch"] / 256.0, peak=fam["grbm_gui_active_per_launch"] / 8.0, unit="cycles per CU per launch",
+                                        frac=(fam["ta_busy_cycles_per_launch"] / 256.0) / (fam["grbm_gui_active_per_launch"] / 8.0),
+                                        addr_stalled_by_tc_frac=(fam.get("ta_addr_stalled_by_tc_per_launch", 0.0) / 256.0) / (fam["grbm_gui_active_per_launch"] / 8.0))
                 if fam.get("l2_read_bytes_per_launch"):
                     d["l2"] = dict(achieved=fam["l2_read_bytes_per_launch"] / avg_s / 1e9, peak=L2_PEAK_GBPS, unit="GB/s", frac=fam["l2_read_bytes_per_launch"] / avg_s / 1e9 / L2_PEAK_GBPS)
                 return d
@@ -469,8 +483,8 @@ def main():
                 per = solo.rays
                 alg_closest = (32.0 * counters["node_tests_per_ray"] + 36.0 * counters["shape_tests_per_ray"] + 48.0) * per
                 alg_any = (32.0 * counters["shadow_node_tests_per_ray"] + 36.0 * counters["shadow_shape_tests_per_ray"]) * per + 36.0 * solo.shadow_rays
-            fam_closest = family("k_trace_closest", "closest", ["k_trace_closest_pt", "k_trace_closest_packet"], solo.seconds_trace, solo.trace_launches, solo.rays, alg_closest)
-            fam_any = family("k_trace_any", "any", ["k_trace_any_pt", "k_trace_any_packet"], solo.seconds_shadow, solo.shadow_launches, solo.shadow_rays, alg_any)
+            fam_closest = family("k_trace_closest", "closest", ["k_trace_closest_pt", "k_trace_closest_packet"], solo.seconds_trace, solo.trace_launches, solo.rays, alg_closest, 32.0)
+            fam_any = family("k_trace_any", "any", ["k_trace_any_pt", "k_trace_any_packet"], solo.seconds_shadow, solo.shadow_launches, solo.shadow_rays, alg_any, 36.0)
             roofline, other = (fam_any, fam_closest) if solo.seconds_shadow > solo.seconds_trace else (fam_closest, fam_any)
             roofline["other"] = other
             roofline["gather_ceiling"] = dict(l1_resident=ceil_l1, at_table_size=ceil_tab, table_bytes=table_bytes,
@@ -480,7 +494,7 @@ def main():
                 for k in ("frac",):
                     if f.get(k) is not None and f[k] > 1.0:
                         raise SystemExit(f"[bench] roofline {f['kernel']}.{k} = {f[k]:.3f} > 1")
-                for sub in ("vector_memory", "l2"):
+                for sub in ("vector_memory", "l2", "ta_busy"):
                     if sub in f and f[sub]["frac"] > 1.0:
                         raise SystemExit(f"[bench] roofline {f['kernel']}.{sub}.frac = {f[sub]['frac']:.3f} > 1")
         out = {

@@ -57,11 +57,33 @@ impl Drop for HipDevice {
 }
 
 impl HipDevice {
-    /// Flattens `Scene` (scene/mod.rs:41-49) into `yk_scene_desc` and uploads it.
-    /// `scene.shapes` is already in BVH leaf order (bvh.rs:96 returns the reordered vec), and
-    /// the library rebuilds the same hierarchy from `shape_order` = identity over that order,
-    /// so the device BVH visits primitives exactly like `scene.bvh`.
+    /// One device: flatten the scene, create a context there, upload.
     pub fn new(scene: &Scene, device: i32) -> Result<Self, String> {
+        flatten_scene(scene, |desc| unsafe {
+            let mut ctx = ptr::null_mut();
+            let st = sys::yk_context_create(device, &mut ctx);
+            if st != sys::YK_OK {
+                return Err(format!("yk_context_create: status {st}"));
+            }
+            let mut scn = ptr::null_mut();
+            let st = sys::yk_scene_create(ctx, desc, &mut scn);
+            if st != sys::YK_OK {
+                let why = sys::last_error(ctx);
+                sys::yk_context_destroy(ctx);
+                return Err(format!("yk_scene_create: {why}"));
+            }
+            Ok(Self { ctx, scene: scn })
+        })
+    }
+}
+
+/// Flattens `Scene` (scene/mod.rs:41-49) into a `yk_scene_desc` that lives for the duration of `f`
+/// (the description borrows the vectors built here; the library copies what it keeps).
+/// `scene.shapes` is already in BVH leaf order (bvh.rs:96 returns the reordered vec), and
+/// the library rebuilds the same hierarchy from `shape_order` = identity over that order,
+/// so the device BVH visits primitives exactly like `scene.bvh`.
+pub(crate) fn flatten_scene<R>(scene: &Scene, f: impl FnOnce(&sys::yk_scene_desc) -> R) -> R {
+    {
         let mut mesh_ids: HashMap<usize, u32> = HashMap::new();
         let mut mat_ids: HashMap<usize, i32> = HashMap::new();
         let mut light_ids: HashMap<usize, i32> = HashMap::new();
@@ -253,21 +275,7 @@ impl HipDevice {
             n_textures: textures.len() as u32,
             textures: textures.as_ptr(),
         };
-        unsafe {
-            let mut ctx = ptr::null_mut();
-            let st = sys::yk_context_create(device, &mut ctx);
-            if st != sys::YK_OK {
-                return Err(format!("yk_context_create: status {st}"));
-            }
-            let mut scn = ptr::null_mut();
-            let st = sys::yk_scene_create(ctx, &desc, &mut scn);
-            if st != sys::YK_OK {
-                let why = sys::last_error(ctx);
-                sys::yk_context_destroy(ctx);
-                return Err(format!("yk_scene_create: {why}"));
-            }
-            Ok(Self { ctx, scene: scn })
-        }
+        f(&desc)
     }
 }
 
@@ -337,6 +345,13 @@ impl Integrator for HipPath {
             return 0;
         }
         let (cam, smp, integ) = (camera_desc(camera), sampler_desc(sampler.as_ref()), self.desc);
+        // the predicate the worker polls per sample (integrators/mod.rs:153) is polled by the library between batches
+        unsafe extern "C" fn poll(user: *mut c_void) -> std::os::raw::c_int {
+            let pred = &mut *(user as *mut &mut dyn FnMut() -> bool);
+            pred() as std::os::raw::c_int
+        }
+        let mut pred_ref: &mut dyn FnMut() -> bool = early_termination_predicate;
+        let user = &mut pred_ref as *mut &mut dyn FnMut() -> bool as *mut c_void;
         let t = sys::yk_tile { x0: tile.bb.p_min.x, y0: tile.bb.p_min.y, x1: tile.bb.p_max.x, y1: tile.bb.p_max.y };
         let mut stats = sys::yk_render_stats::default();
         // Spectrum<f32> is three packed f32 (math/spectrum.rs:45-55)
@@ -344,11 +359,14 @@ impl Integrator for HipPath {
         let st = unsafe {
             if accumulating {
                 let sample = tile.sample as u16; // types_fit, integrators/mod.rs:140-141
-                sys::yk_render_tiles_accumulating(self.gpu.ctx, self.gpu.scene, &cam, &smp, &integ, &t, &sample, 1, out, &mut stats, None, ptr::null_mut::<c_void>())
+                sys::yk_render_tiles_accumulating(self.gpu.ctx, self.gpu.scene, &cam, &smp, &integ, &t, &sample, 1, out, &mut stats, Some(poll), user)
             } else {
-                sys::yk_render_tiles(self.gpu.ctx, self.gpu.scene, &cam, &smp, &integ, &t, 1, out, &mut stats, None, ptr::null_mut::<c_void>())
+                sys::yk_render_tiles(self.gpu.ctx, self.gpu.scene, &cam, &smp, &integ, &t, 1, out, &mut stats, Some(poll), user)
             }
         };
+        if st == sys::YK_ERR_CANCELLED {
+            return 0; // tile contents undefined, discarded by the caller like render_worker.rs:252-255
+        }
         assert_eq!(st, sys::YK_OK, "HIP render failed: {}", sys::last_error(self.gpu.ctx));
         stats.rays as usize
     }

@@ -526,6 +526,51 @@ void orc_bounds_ops_f32(const float* bmin, const float* bmax, const float* p, fl
     out[4] = b.volume();
     out[5] = (float)b.maximum_extent();
 }
+void orc_math_kat_f32(int op, const float* a, const float* b, float* out) {
+    Vec3f va(a[0], a[1], a[2]);
+    Vec3f vb = b ? Vec3f(b[0], b[1], b[2]) : Vec3f();
+    auto put3 = [&](float x, float y, float z) { out[0] = x; out[1] = y; out[2] = z; };
+    auto box = [](const float* q) {
+        Bounds3f r;
+        r.p_min = Point3f(q[0], q[1], q[2]);
+        r.p_max = Point3f(q[3], q[4], q[5]);
+        return r;
+    };
+    auto put_box = [&](const Bounds3f& r) {
+        out[0] = r.p_min.x; out[1] = r.p_min.y; out[2] = r.p_min.z;
+        out[3] = r.p_max.x; out[4] = r.p_max.y; out[5] = r.p_max.z;
+    };
+    switch (op) {
+        case 0: { Vec3f r = va.vmin(vb); put3(r.x, r.y, r.z); break; }
+        case 1: { Vec3f r = va.vmax(vb); put3(r.x, r.y, r.z); break; }
+        case 2: out[0] = va.min_comp(); break;
+        case 3: out[0] = va.max_comp(); break;
+        case 4: out[0] = (float)va.max_dimension(); break;
+        case 5: { Vec3f r = va.permuted((int)b[0], (int)b[1], (int)b[2]); put3(r.x, r.y, r.z); break; }
+        case 6: { Vec3f r = va.abs(); put3(r.x, r.y, r.z); break; }
+        case 7: { Vec3f r = -va; put3(r.x, r.y, r.z); break; }
+        case 8: {  // impl_point.rs:39-49: (1 - t) * self + t * other, per component
+            const float t = b[3];
+            put3((1.0f - t) * a[0] + t * b[0], (1.0f - t) * a[1] + t * b[1], (1.0f - t) * a[2] + t * b[2]);
+            break;
+        }
+        case 20:  // Bounds3::lerp, impl_bounds.rs:101-111: (1 - t.c) * p_min.c + t.c * p_max.c
+            put3((1.0f - b[0]) * a[0] + b[0] * a[3], (1.0f - b[1]) * a[1] + b[1] * a[4], (1.0f - b[2]) * a[2] + b[2] * a[5]);
+            break;
+        case 9: put_box(box(a).union_b(box(b))); break;
+        case 10: put_box(box(a).union_p(Point3f(b[0], b[1], b[2]))); break;
+        case 11: { Vec3f r = box(a).diagonal(); put3(r.x, r.y, r.z); break; }
+        case 12: out[0] = box(a).inside(Point3f(b[0], b[1], b[2])) ? 1.0f : 0.0f; break;
+        case 13: { Rayf r(Point3f(a[0], a[1], a[2]), Vec3f(a[3], a[4], a[5]), 1.0f); Point3f q = r.point(b[0]); put3(q.x, q.y, q.z); break; }
+        case 14: out[0] = Normalf(a[0], a[1], a[2]).dot(Normalf(b[0], b[1], b[2])); break;
+        case 15: out[0] = Normalf(a[0], a[1], a[2]).len_sqr(); break;
+        case 16: out[0] = Point3f(a[0], a[1], a[2]).dist(Point3f(b[0], b[1], b[2])); break;
+        case 17: out[0] = Point3f(a[0], a[1], a[2]).dist_sqr(Point3f(b[0], b[1], b[2])); break;
+        case 18: out[0] = va.len_sqr(); break;
+        case 19: put_box(Bounds3f(Point3f(a[0], a[1], a[2]), Point3f(b[0], b[1], b[2]))); break;
+        default: out[0] = 0.0f;
+    }
+}
 void orc_coordinate_system_f32(const float* v, float* v1, float* v2) {
     Vec3f a, b;
     coordinate_system(Vec3f(v[0], v[1], v[2]), a, b);

@@ -196,6 +196,13 @@ void orc_rotation_f32(int axis, float theta, const float* axis_v, float* m, floa
 void orc_vec3_ops_f32(const float* a, const float* b, float* out /* cross[3], dot, len(a), normalized(a)[3], max_dim(a) */);
 void orc_bounds_ops_f32(const float* bmin, const float* bmax, const float* p, float* out /* offset[3], area, volume, max_extent */);
 void orc_coordinate_system_f32(const float* v, float* v1, float* v2);
+/* The rest of the reference's math unit tests (tests/src/{bounds,point,normal,vector,ray}.rs) replayed one operation at a
+ * time.  a, b: up to 6 floats each (a box is min xyz, max xyz); out: up to 6 floats.  op:
+ *   0 Vec3::min  1 Vec3::max  2 min_comp  3 max_comp  4 max_dimension  5 permuted(a; b = indices)  6 abs  7 neg
+ *   8 Point3::lerp(a, b, t = b[3])  9 Bounds3::union_b  10 Bounds3::union_p(a, p = b)  11 Bounds3::diagonal
+ *   12 Bounds3::inside(a, p = b) -> 0/1  13 Ray::point(o = a[0..3], d = a[3..6], t = b[0])  14 Normal::dot  15 Normal::len_sqr
+ *   16 Point3::dist  17 Point3::dist_sqr  18 Vec3::len_sqr  19 Bounds3::new(p0 = a, p1 = b) (sorted corners)  20 Bounds3::lerp(a, t = b) */
+void orc_math_kat_f32(int op, const float* a, const float* b, float* out);
 int orc_slab_test_f32(const float* bmin, const float* bmax, const float* o, const float* d, float t_max, float* tmin,
                       float* tmax);
 

@@ -387,7 +387,7 @@ def test_max_depth_zero_renders_black(ctx, yk, oracle):
 def test_tie_hits_that_raise_t_max(yk, oracle, wide):
     """Slabs of overlapping coplanar triangles: a tie hit can set t_max a few ulps ABOVE the old value
     (triangle.rs:126-139), and a far box culled when its parent was visited passes when the reference
-    pops it.  With the exact bound for deferred boxes (build with -DYK_EXACT_DEFERRED_BOUND) the node
+    pops it.  With the exact bound for deferred boxes (tools/build_variant.sh exact -DYK_DEFERRED_BOUND_FACTOR=1.0f) the node
     counters of this scene differ in three values; with the relaxed bound everything is identical."""
     sd = scenes.by_name("coplanar-slabs")
     c = yk.Context(0, wide_bvh=wide)

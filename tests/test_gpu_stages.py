@@ -220,3 +220,55 @@ def test_degenerate_rays_on_random_scenes(oracle, seed):
     import stage_fuzz
 
     assert stage_fuzz.check_seed(oracle, seed) == []
+
+
+def test_device_vector_math_replays_the_reference_kats_and_matches_the_oracle(ctx, yk, oracle):
+    """The reference's own vector known-answer values (tests/src/vector.rs, normal.rs — tests/golden/reference_math_kats.json)
+    through the DEVICE versions of those functions (yk_math.h, used by every kernel), then 30,000 random triples against the
+    oracle's, bit for bit: dot, the f64 cross product, len, normalized, max_dimension, abs, Normal::dot_v, min, max,
+    faceforward, and the axis permutation Triangle::intersect derives from a ray direction (triangle.rs:60-66)."""
+    import ctypes as C
+    import json
+    import os
+
+    kats = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_math_kats.json")))
+    f32 = lambda v: np.ascontiguousarray(v, dtype=np.float32)  # noqa: E731
+    v = kats["vector"]
+    assert yk.device_math(ctx, 11, f32(v["dot"]["a"]), f32(v["dot"]["b"]))[0] == v["dot"]["expect"]
+    assert np.array_equal(yk.device_math(ctx, 12, f32(v["cross"]["a"]), f32(v["cross"]["b"])), f32(v["cross"]["expect"]))
+    a = f32(v["len"]["a"])
+    assert yk.device_math(ctx, 13, a)[0] == np.sqrt(np.float32(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]))
+    assert abs(np.linalg.norm(yk.device_math(ctx, 14, f32(v["normalized"]["a"])).astype(np.float64)) - 1.0) < 1e-6
+    assert yk.device_math(ctx, 15, f32(v["max_dimension"]["a"]))[0] == v["max_dimension"]["expect"]
+    assert yk.device_math(ctx, 17, f32(kats["normal"]["n"]), f32(kats["normal"]["v"]))[0] == kats["normal"]["dot_v"]
+    dev_of = {0: 19, 1: 20, 4: 15, 6: 16}  # orc_math_kat_f32 op -> yk_device_math fn, where the function exists on the device
+    replayed = 0
+    for c in kats["more"]["cases"]:
+        if c["op"] in dev_of:
+            got = yk.device_math(ctx, dev_of[c["op"]], f32(c["a"]), None if c["b"] is None else f32(c["b"]))
+            assert np.array_equal(got[: len(c["expect"])], f32(c["expect"])), c["name"]
+            replayed += 1
+    assert replayed >= 7
+    # tie rules of Vec3::max_dimension (vector.rs:181-195)
+    for t, e in (([1, 1, 1], 2), ([2, 1, 2], 2), ([2, 2, 1], 1), ([3, 1, 2], 0)):
+        assert yk.device_math(ctx, 15, f32(t))[0] == e
+    # random triples against the oracle
+    rng = np.random.default_rng(5)
+    n = 30000
+    A = (rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-3, 3, (n, 1))).astype(np.float32)
+    B = (rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-3, 3, (n, 1))).astype(np.float32)
+    A[:50, 0] = 0.0
+    A[50:100] = np.abs(A[50:100, :1])  # equal components: the tie rules
+    L = oracle.lib()
+    want = np.zeros((n, 9), dtype=np.float32)
+    for k in range(n):
+        L.orc_vec3_ops_f32(A[k].ctypes.data_as(C.c_void_p), B[k].ctypes.data_as(C.c_void_p), want[k].ctypes.data_as(C.c_void_p))
+    flatA, flatB = A.reshape(-1), B.reshape(-1)
+    assert np.array_equal(_bits(yk.device_math(ctx, 12, flatA, flatB).reshape(n, 3)), _bits(want[:, 0:3]))
+    assert np.array_equal(_bits(yk.device_math(ctx, 11, flatA, flatB).reshape(n, 3)[:, 0]), _bits(want[:, 3]))
+    assert np.array_equal(_bits(yk.device_math(ctx, 13, flatA).reshape(n, 3)[:, 0]), _bits(want[:, 4]))
+    assert np.array_equal(_bits(yk.device_math(ctx, 14, flatA).reshape(n, 3)), _bits(want[:, 5:8]))
+    assert np.array_equal(yk.device_math(ctx, 15, flatA).reshape(n, 3)[:, 0], want[:, 8])
+    kz = yk.device_math(ctx, 15, np.abs(flatA)).reshape(n, 3)[:, 0]
+    perm = yk.device_math(ctx, 18, flatA).reshape(n, 3)
+    assert np.array_equal(perm[:, 2], kz) and np.array_equal(perm[:, 0], (kz + 1) % 3) and np.array_equal(perm[:, 1], (kz + 2) % 3)

@@ -200,3 +200,41 @@ def test_coordinate_system_quirk(oracle):
     L.orc_coordinate_system_f32(_p(v), _p(v1), _p(v2))
     den = np.sqrt(np.float32(v[0] * v[0] + v[2] * v[2]))
     assert np.array_equal(v1, f32([-v[2] / den, 0.0, v[0] / den]))
+
+
+def _kat(L, op, a, b):
+    out = np.full(6, np.nan, dtype=np.float32)
+    aa = f32(a)
+    bb = None if b is None else f32(b)
+    L.orc_math_kat_f32(op, _p(aa), None if bb is None else _p(bb), _p(out))
+    return out
+
+
+def test_remaining_reference_math_tests(oracle):
+    """The path-relevant remainder of tests/src/{bounds,point,normal,vector,ray}.rs (KATS["more"]), one operation per case:
+    exact equality, as the reference's assert_eq! / assert_abs_diff_eq! (default epsilon) on these values demand."""
+    L = oracle.lib()
+    more = KATS["more"]
+    assert len(more["cases"]) >= 30
+    for c in more["cases"]:
+        got = _kat(L, c["op"], c["a"], c["b"])
+        want = f32(c["expect"])
+        assert np.array_equal(got[: len(want)], want), (c["name"], got, want, c["source"])
+    out = np.zeros(6, dtype=np.float32)
+    for c in more["surface_area_more"]:
+        box = _kat(L, 19, c["min"], c["max"])  # Bounds3::new sorts the corners first
+        L.orc_bounds_ops_f32(_p(f32(box[:3])), _p(f32(box[3:])), _p(f32(box[:3])), _p(out))
+        assert out[3] == c["expect"]
+    for c in more["volume_more"]:
+        box = _kat(L, 19, c["min"], c["max"])
+        L.orc_bounds_ops_f32(_p(f32(box[:3])), _p(f32(box[3:])), _p(f32(box[:3])), _p(out))
+        assert out[4] == c["expect"]
+    for c in more["maximum_extent_more"]:
+        L.orc_bounds_ops_f32(_p(f32(c["min"])), _p(f32(c["max"])), _p(f32(c["min"])), _p(out))
+        assert out[5] == c["expect"]
+    # Bounds3::bounding_sphere (bounds.rs:156-169 of the crate): centre = (p_min + p_max) / 2, radius = dist(centre, p_max)
+    bs = more["bounding_sphere"]
+    centre = (f32(bs["min"]) + f32(bs["max"])) / np.float32(2)
+    assert np.array_equal(centre, f32(bs["center"]))
+    r = _kat(L, 16, centre, bs["max"])[0]
+    assert r == np.sqrt(np.float32(3 * 1.5 * 1.5))

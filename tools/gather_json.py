@@ -44,7 +44,7 @@ if len(sys.argv) > 2:
         if per:
             last = per[sorted(per, key=int)[-1]]
             n_rec = 256 * 6 * 256 * 2000
-            cal = dict(table_kb=int(os.path.basename(os.path.dirname(os.path.dirname(os.path.dirname(f))))[8:]), records=n_rec, counters=last,
+            cal = dict(table_kb=int(re.search(r"fetch_kb(\d+)", f).group(1)), records=n_rec, counters=last,
                        fetch_size_bytes_per_record=last.get("FETCH_SIZE", 0.0) * 1024.0 / n_rec, ea_rdreq_per_record=last.get("TCC_EA0_RDREQ_sum", 0.0) / n_rec,
                        note="random 64-byte records of a 1 GB table (beyond L2 and Infinity Cache): FETCH_SIZE (KiB as reported) per record tells what one 64-byte gather costs in counted bytes")
 out = dict(what="per-lane gathers of random 64-byte records (4 x global_load_dwordx4 per lane), 1536 blocks x 256 threads x 2000 dependent iterations, MI355X",

@@ -13,10 +13,9 @@ def per_launch(ks, counter, scale=1.0):
 
 for fam in ("closest", "any"):
     ks = [f"k_trace_{fam}_pt", f"k_trace_{fam}_packet"]
-    fetch, n = per_launch(ks, "FETCH_SIZE", 1024.0 * 2.0)
+    fetch, n = per_launch(ks, "FETCH_SIZE", 1024.0)
     write, _ = per_launch(ks, "WRITE_SIZE", 1024.0)
-    o = {"kernels": ks, "dispatches": n, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
-         "hbm_bytes_per_launch": (fetch or 0.0) + (write or 0.0) if fetch is not None else None}
+    o = {"kernels": ks, "dispatches": n, "fetch_size_bytes_per_launch": fetch, "write_size_bytes_per_launch": write}
     for name, counter, scale in (("tcp_accesses_per_launch", "TCP_TOTAL_ACCESSES_sum", 1.0), ("tcp_cache_accesses_per_launch", "TCP_TOTAL_CACHE_ACCESSES_sum", 1.0),
                                  ("l2_read_req_per_launch", "TCP_TCC_READ_REQ_sum", 1.0), ("tcp_pending_stall_cycles_per_launch", "TCP_PENDING_STALL_CYCLES_sum", 1.0),
                                  ("ta_busy_cycles_per_launch", "TA_TA_BUSY_sum", 1.0), ("ta_flat_read_wavefronts_per_launch", "TA_FLAT_READ_WAVEFRONTS_sum", 1.0),
@@ -26,10 +25,15 @@ for fam in ("closest", "any"):
         v, _ = per_launch(ks, counter, scale)
         if v is not None:
             o[name] = v
+    thr, _ = per_launch(ks, "SQ_THREAD_CYCLES_VALU")
+    act, _ = per_launch(ks, "SQ_ACTIVE_INST_VALU")
+    if thr and act:
+        o["valu_lane_utilisation"] = thr / (64.0 * act)
     if "l2_read_req_per_launch" in o:
         o["l2_read_bytes_per_launch"] = o["l2_read_req_per_launch"] * 64.0  # TCP->TCC read requests are 64-byte
     out[fam] = o
-out["note"] = ("per kernel family, averaged over all its launches of the run; FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide "
-               "coalesced reads; node/triangle gathers are 16-B-per-lane loads but not streaming, so the corrected figure is an upper bound); WRITE_SIZE as reported; "
-               "FETCH_SIZE counts Infinity-Cache hits too: an upper bound on DRAM traffic")
+out["note"] = ("per kernel family, averaged over all its launches of the run.  FETCH_SIZE / WRITE_SIZE are the counters as reported (KiB -> bytes), uncorrected: "
+               "on gfx950 FETCH_SIZE counts a wide coalesced streaming read at 1/2 of its bytes (MI355X_MICROARCH.md) but a per-lane 64-byte gather at its full size "
+               "(calibrated: profiles/r02_gather_bench.json, fetch_size_calibration: 65.5 counted bytes per 64-byte record of a 1 GB table); bench.py adds the missing "
+               "half of the streamed ray records.  FETCH_SIZE counts Infinity-Cache hits too: an upper bound on DRAM traffic")
 json.dump(out, sys.stdout, indent=1)

@@ -46,7 +46,7 @@ static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
 // ref bit 30: index into DevScene::top_nodes (the first levels of the tree, which the
 // traversal kernels keep in LDS) instead of DevScene::nodes
 #define YK_TOP_BIT 0x40000000u
-#define YK_TOP_MAX 255
+#define YK_TOP_MAX 1023
 
 // 128-byte (one cache line) 4-wide node: a reference interior node P collapsed with its two
 // children A = P+1 and B = second child.  Slots 0,1 = A's children (or A itself + NONE when

@@ -90,12 +90,19 @@ YK_HD bool slab(V3 lo, V3 hi, V3 o, V3 inv, float t_max, float& tmin) {
 // reference: the watertight triangle test accepts t_scaled <= t_max * det and returns
 // t = t_scaled / det (triangle.rs:126-139, no conservative t-error test), so a tie hit among
 // coplanar triangles can RAISE t_max by a few ulps, and a box culled at visit time by the
-// exact bound would pass at pop time.  2^-10 relative covers thousands of such raises.
-#ifdef YK_EXACT_DEFERRED_BOUND  // build variant for tests/tools only: the pre-fix behaviour, to show that a test scene exercises the case
-YK_HD float deferred_t_max(float t_max) { return t_max; }
-#else
-YK_HD float deferred_t_max(float t_max) { return t_max * 1.0009765625f; }
+// exact bound would pass at pop time.
+// LIMIT of the relaxed bound: it holds while t_max rises by no more than 2^-10 relative between the
+// visit of a parent and the pop of its deferred child.  One tie hit lifts t_max by at most a few ulps
+// (<= ~2^-21 relative), so the bound covers chains of roughly a thousand successive raises on one ray inside
+// one such window — thousands of exactly coplanar, overlapping duplicates along a ray are outside it
+// (the randomised parity runs, slabs of 160 coplanar triangles each, stay far inside).  Beyond the
+// limit a deferred box could be culled that the reference would still enter; nothing else changes.
+// (Tools-only builds set the factor to 1.0f to show that a scene exercises the case:
+// tools/build_variant.sh exact -DYK_DEFERRED_BOUND_FACTOR=1.0f.)
+#ifndef YK_DEFERRED_BOUND_FACTOR
+#define YK_DEFERRED_BOUND_FACTOR 1.0009765625f  // 1 + 2^-10
 #endif
+YK_HD float deferred_t_max(float t_max) { return t_max * YK_DEFERRED_BOUND_FACTOR; }
 
 // SurfaceInteraction after Triangle::intersect, triangle.rs:141-226 +
 // interaction.rs:95-132 — the fields the integrator reads.

@@ -19,6 +19,7 @@
 #include "yk_geom.h"
 #include "yk_kernels.h"
 #include "yk_rng.h"
+#include "yk_shade.h"
 #include "yk_wave.h"
 
 namespace yk {
@@ -230,7 +231,6 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
         }
         float4 nO = make_float4(0, 0, 0, 0), nD = nO, nT = nO;
         uint4 nR = make_uint4(0, 0, 0, 0);
-        // per-light scratch lives in registers only for the current light
         V3 o = V3{0, 0, 0}, d = V3{0, 0, 1};
         RGB beta = RGB{0, 0, 0};
         unsigned flags = 0, sid = 0, bounces = 0;
@@ -239,15 +239,14 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
         st.rng.state = 0;
         st.rng.inc = 1;
         st.px = st.py = st.sample_index = st.dimension = 0;
-        Surface sf;
-        sf.p = sf.n = sf.ns = sf.dpdus = sf.wo = V3{0, 0, 1};
-        sf.material = 0;
-        sf.area_light = -1;
-        Material mat;
-        mat.kind = MK_BLACK;
-        Frame fr;
-        fr.s = fr.t = fr.n = fr.ng = V3{0, 0, 1};
-        V3 wo = V3{0, 0, 1};
+        PathVertex v;  // lanes without a hit never read it; the defaults keep their registers defined
+        v.sf.p = v.sf.n = v.sf.ns = v.sf.dpdus = v.sf.wo = V3{0, 0, 1};
+        v.sf.material = 0;
+        v.sf.area_light = -1;
+        v.sf.u = v.sf.v = 0.0f;
+        v.mat.kind = MK_BLACK;
+        v.fr.s = v.fr.t = v.fr.n = v.fr.ng = V3{0, 0, 1};
+        v.wo = V3{0, 0, 1};
         if (valid) {
             float4 a = cur.rayO[i], b = cur.rayD[i], c = cur.thru[i];
             uint4 r = cur.rngs[i];
@@ -269,45 +268,20 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
             st.sample_index = (sample_index_tab ? sample_index_tab[pix] : 0u) + sid % prm.spe;
             int tri = hit_tri[i];
             hit = tri >= 0;
-            if (hit) {
-                sf = hit_surface_prim(sc, (uint32_t)tri, o, d);  // `tri` is the leaf-order slot reported by the render-loop trace kernels
-                mat = sc.materials[sf.material];
-                if (mat.tex) {  // matte.rs:29-30: reflectance = kd.evaluate(si); no lobe when black
-                    RGB kd = texture_eval(sc, mat.tex - 1u, sf.u, sf.v);
-                    mat.a[0] = kd.r;
-                    mat.a[1] = kd.g;
-                    mat.a[2] = kd.b;
-                    if (is_black(kd)) mat.kind = MK_BLACK;
-                }
-                fr = make_frame(sf.n, sf.ns, sf.dpdus);
-                wo = -d;
-            }
+            if (hit) vertex_setup(sc, (uint32_t)tri, o, d, v);  // `tri` is the leaf-order slot reported by the render-loop trace kernels
         }
         // ---- next-event estimation over ALL lights (path.rs:102-119); two sampler
         // dimensions are consumed per light whether or not it contributes.
         for (unsigned l = 0; l < nl; ++l) {
-            bool want = false;
             unsigned slot = i * nl + l;
-            RGB contrib = RGB{0, 0, 0};
-            V3 so = V3{0, 0, 0}, sd = V3{0, 0, 1};
-            int al = -1;
-            if (valid && hit) {
-                float ux, uy;
-                sampler_get_2d(prm.sampler, st, ux, uy);
-                LightSample ls = sample_light(sc.lights[l], (int)l, sf.p, ux, uy);
-                if (!is_black(ls.li)) {
-                    RGB f = bsdf_f(mat, fr, sf.wo, ls.l);  // path.rs:105 uses si.wo
-                    if (ls.has_vis && !is_black(f)) {
-                        contrib = f * ls.li * rclamp(dot_nv(sf.ns, ls.l), 0.0f, 1.0f) / ls.pdf;
-                        // VisibilityTester::ray = p0.spawn_ray_to(p1), interaction.rs:44-59
-                        V3 offset = sf.n * 0.001f;
-                        so = dot(ls.p1 - sf.p, sf.n) > 0.0f ? sf.p + offset : sf.p - offset;
-                        sd = ls.p1 - so;
-                        al = ls.area_light;
-                        want = true;
-                    }
-                }
-            }
+            NeeSample ne;
+            ne.want = false;
+            ne.contrib = RGB{0, 0, 0};
+            ne.so = V3{0, 0, 0};
+            ne.sd = V3{0, 0, 1};
+            ne.al = -1;
+            if (valid && hit) ne = vertex_light(sc, prm, st, l, v);
+            const bool want = ne.want;
             if (valid) vis[slot] = want ? 1 : 0;
             // shadow rays are appended densely (coalesced for the any-hit kernel); the
             // contribution stays at its (path, light) slot for `accumulate`
@@ -321,52 +295,26 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
             }
             unsigned q = block_append(want, &stg.fill_q);
             if (want) {
-                stg.qO[q] = make_float4(so.x, so.y, so.z, 0.9999f);
-                stg.qD[q] = make_float4(sd.x, sd.y, sd.z, __uint_as_float((unsigned)al));
+                stg.qO[q] = make_float4(ne.so.x, ne.so.y, ne.so.z, 0.9999f);
+                stg.qD[q] = make_float4(ne.sd.x, ne.sd.y, ne.sd.z, __uint_as_float((unsigned)ne.al));
                 stg.qS[q] = slot;
-                shC[slot] = make_float4(contrib.r, contrib.g, contrib.b, 0.0f);
+                shC[slot] = make_float4(ne.contrib.r, ne.contrib.g, ne.contrib.b, 0.0f);
             }
         }
         if (valid) {
-            // kind bits: 1 = miss, 2 = emission term present, 4 = indirect clamp applies
             unsigned kind = 0;
             RGB term = RGB{0, 0, 0};
             if (!hit) {
-                // path.rs:155-160: incoming_radiance += beta * scene.background; break
-                term = beta * RGB{sc.background[0], sc.background[1], sc.background[2]};
-                kind = 1;
+                term = vertex_miss_term(sc, beta);
+                kind = YK_PEND_MISS;
             } else {
-                if (bounces == 0 || specular_bounce) {  // path.rs:121-123
-                    RGB le = RGB{0, 0, 0};
-                    if (sf.area_light >= 0) {
-                        const DevLight& L = sc.lights[sf.area_light];
-                        le = dot_nv(sf.n, wo) > 0.0f ? RGB{L.i[0], L.i[1], L.i[2]} : RGB{0, 0, 0};  // rectangular_light.rs:75-81
-                    }
-                    term = beta * le;
-                    kind |= 2;
-                }
-                if (bounces > 0 && prm.has_clamp) kind |= 4;
-                // path.rs:131-145
-                float ux, uy;
-                sampler_get_2d(prm.sampler, st, ux, uy);
-                BsdfSample bs = bsdf_sample_f(mat, fr, wo, ux, uy);
-                if (!(is_black(bs.f) || bs.pdf == 0.0f)) {
-                    specular_bounce = (bs.type & BX_SPECULAR) != 0;
-                    beta = beta * (bs.f * fabsf(dot_nv(bs.wi, sf.ns)) / bs.pdf);
-                    V3 no = spawn_origin(sf.p, sf.n, bs.wi);
-                    alive = true;
-                    // Russian roulette, path.rs:162-169
-                    if (bounces > 3) {
-                        float q = rmax(1.0f - beta.g, 0.05f);
-                        if (sampler_get_1d(prm.sampler, st) < q)
-                            alive = false;
-                        else
-                            beta = beta * (RGB{1.0f, 1.0f, 1.0f} / (1.0f - q));
-                    }
-                    bounces += 1;
-                    if (!(bounces < prm.max_depth)) alive = false;  // while bounces < max_depth
-                    nO = make_float4(no.x, no.y, no.z, __uint_as_float((bounces & 0xffu) | (specular_bounce ? 0x100u : 0u)));
-                    nD = make_float4(bs.wi.x, bs.wi.y, bs.wi.z, __uint_as_float(sid));
+                VertexEnd e = vertex_finish(sc, prm, st, v, beta, bounces, specular_bounce);
+                term = e.term;
+                kind = e.kind;
+                alive = e.alive;
+                if (e.sampled) {
+                    nO = make_float4(e.no.x, e.no.y, e.no.z, __uint_as_float((bounces & 0xffu) | (specular_bounce ? 0x100u : 0u)));
+                    nD = make_float4(e.wi.x, e.wi.y, e.wi.z, __uint_as_float(sid));
                     nT = make_float4(beta.r, beta.g, beta.b, __uint_as_float(st.dimension));
                     nR = make_uint4((unsigned)st.rng.state, (unsigned)(st.rng.state >> 32), (unsigned)st.rng.inc, (unsigned)(st.rng.inc >> 32));
                 }
@@ -410,10 +358,8 @@ __global__ void k_accumulate(RenderParams prm, PathBuffers cur, const float4* pe
         RGB beta = RGB{c.x, c.y, c.z};
         float4 acc = sample_buf[sid];
         RGB L = RGB{acc.x, acc.y, acc.z};
-        if (kind & 1u) {
-            L = L + RGB{p.x, p.y, p.z};
-        } else {
-            RGB radiance = RGB{0.0f, 0.0f, 0.0f};
+        RGB radiance = RGB{0.0f, 0.0f, 0.0f};
+        if (!(kind & YK_PEND_MISS)) {
             for (unsigned l = 0; l < nl; ++l) {
                 unsigned slot = i * nl + l;
                 if (vis[slot] == 1) {
@@ -421,10 +367,8 @@ __global__ void k_accumulate(RenderParams prm, PathBuffers cur, const float4* pe
                     radiance = radiance + RGB{ct.x, ct.y, ct.z};
                 }
             }
-            if (kind & 2u) radiance = radiance + RGB{p.x, p.y, p.z};
-            if (kind & 4u) radiance = rgb_min(radiance, RGB{1.0f, 1.0f, 1.0f} * prm.clamp);
-            L = L + beta * radiance;
         }
+        L = vertex_accumulate(prm, L, beta, radiance, RGB{p.x, p.y, p.z}, kind);
         sample_buf[sid] = make_float4(L.r, L.g, L.b, 0.0f);
     }
 }
@@ -522,6 +466,33 @@ __global__ void k_debug_shade(DevScene sc, uint32_t integrator, PathBuffers cur,
 __global__ void k_device_math(int fn, size_t n, const float* a, const float* b, float* out) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (fn >= 11) {  // vector functions of yk_math.h / yk_geom.h on triples: a, b = n/3 packed V3, thread 3k handles triple k
+        if (i % 3) return;
+        V3 va = V3{a[i], a[i + 1], a[i + 2]}, vb = b ? V3{b[i], b[i + 1], b[i + 2]} : V3{0.0f, 0.0f, 0.0f};
+        V3 r = V3{0.0f, 0.0f, 0.0f};
+        switch (fn) {
+            case 11: r.x = dot(va, vb); break;
+            case 12: r = cross(va, vb); break;
+            case 13: r.x = length(va); break;
+            case 14: r = normalize(va); break;
+            case 15: r.x = (float)max_dimension(va); break;
+            case 16: r = vabs(va); break;
+            case 17: r.x = dot_nv(va, vb); break;
+            case 18: {  // the permutation Triangle::intersect derives from the ray direction (triangle.rs:60-66)
+                RayTri rt = ray_tri_setup(va);
+                r = V3{(float)rt.kx, (float)rt.ky, (float)rt.kz};
+                break;
+            }
+            case 19: r = V3{rmin(va.x, vb.x), rmin(va.y, vb.y), rmin(va.z, vb.z)}; break;
+            case 20: r = V3{rmax(va.x, vb.x), rmax(va.y, vb.y), rmax(va.z, vb.z)}; break;
+            case 21: r = faceforward_v(va, vb); break;
+            default: break;
+        }
+        out[i] = r.x;
+        out[i + 1] = r.y;
+        out[i + 2] = r.z;
+        return;
+    }
     float x = a[i], y = b ? b[i] : 0.0f, r;
     switch (fn) {
         case 0: r = det_sinf(x); break;
