@@ -45,7 +45,7 @@ HBM_COPY_CEILING_GBPS = 6290.0
 L2_PEAK_GBPS = 34500.0  # MI355X_MICROARCH.md §L2: ~34.5 TB/s aggregate
 
 
-def self_launch(args):
+def self_launch(args, stdout_fd):
     """`--gpus N` (N > 1) without a launcher: start the N ranks as children of this process — which has
     not imported torch and never touches HIP — relay their output (rank 0 prints the JSON line) and
     exit with their status.  Never falls through to a one-GPU run."""
@@ -60,7 +60,7 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     log(f"[bench] WORLD_SIZE unset: launching {args.gpus} ranks: {' '.join(cmd)}")
-    rc = subprocess.call(cmd, env=env)
+    rc = subprocess.call(cmd, env=env, stdout=stdout_fd)  # the ranks write the JSON record to this process's real stdout
     raise SystemExit(rc)
 
 
@@ -76,7 +76,7 @@ def gather_ceiling(table_bytes):
     d = json.load(open(os.path.join(ROOT, "profiles", best)))
     rows = sorted(d["tables"], key=lambda r: r["table_bytes"])
     row = next((r for r in rows if r["table_bytes"] >= table_bytes), rows[-1])
-    return dict(GBps=row["GBps"], table_bytes=row["table_bytes"], source=f"profiles/{best}")
+    return dict(GBps=row["GBps"], table_bytes=row["table_bytes"], tcp_accesses_per_s=row.get("tcp_accesses_per_s"), source=f"profiles/{best}")
 
 
 def pmc_traffic(workload):
@@ -144,6 +144,11 @@ def cpu_baseline(sd, cam, sampler, integ, tiles, n_sample_tiles):
 
 
 def main():
+    # Exactly ONE line on stdout, the JSON record: libraries (RCCL's version banner, gloo) print to fd 1 behind Python's
+    # back, so fd 1 points at stderr until the record is written.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -174,7 +179,7 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args)  # does not return; nothing GPU-related has been imported yet
+        self_launch(args, real_stdout)  # does not return; nothing GPU-related has been imported yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -523,7 +528,8 @@ def main():
                       "steps_mode": "asynchronous (no host sync inside the timed region; per-kernel times and ray counts from one untimed probe step)" if async_steps
                       else "synchronous (per-kernel HIP-event times read after every step of the timed region)"},
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     for sl in slots:  # communicators first: they hold their context
         if sl.get("dist"):
             sl["dist"].close()

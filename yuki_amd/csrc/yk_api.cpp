@@ -328,7 +328,7 @@ struct SceneImage {
     uint32_t root_ref = 0;
     std::vector<DevNode> dn, top;
     std::vector<DevNode4> dn4;
-    std::vector<float4> tris, texels;
+    std::vector<float4> tris, texels, prim_attr;
     std::vector<uint4> prim_shade, tex_info;
     std::vector<uint32_t> mesh_flags, tri_mesh;
     std::vector<int32_t> tri_al;
@@ -576,7 +576,7 @@ yk_status yk_build_scene_image(yk_context* ctx, const yk_scene_desc* d, std::sha
         for (size_t p = 0; p < np; ++p) {
             uint32_t src = bvh->shape_order[p];
             if (src >= d->n_triangles) {  // sphere: only the source index and the flags are read
-                uint32_t none = 0xffffffffu, fl = (last[p] ? YK_PRIM_LAST : 0u) | YK_PRIM_SPHERE;
+                uint32_t none = 0xffffffffu, fl = (last[p] ? YK_PRIM_LAST : 0u) | YK_PRIM_SPHERE | (mat_kind[d->spheres[src - d->n_triangles].material] << YK_PRIM_KIND_SHIFT);
                 float w0, w1, w2;
                 std::memcpy(&w0, &none, 4);
                 std::memcpy(&w1, &src, 4);
@@ -591,7 +591,7 @@ yk_status yk_build_scene_image(yk_context* ctx, const yk_scene_desc* d, std::sha
             const float* p1 = d->points + 3 * (size_t)d->indices[3 * src + 1];
             const float* p2 = d->points + 3 * (size_t)d->indices[3 * src + 2];
             int al = d->tri_area_light ? d->tri_area_light[src] : -1;
-            uint32_t alb = (uint32_t)al, lastb = last[p] ? YK_PRIM_LAST : 0u;
+            uint32_t alb = (uint32_t)al, lastb = (last[p] ? YK_PRIM_LAST : 0u) | (mat_kind[d->tri_material[src]] << YK_PRIM_KIND_SHIFT);
             float w0, w1, w2;
             std::memcpy(&w0, &alb, 4);
             std::memcpy(&w1, &src, 4);
@@ -603,6 +603,26 @@ yk_status yk_build_scene_image(yk_context* ctx, const yk_scene_desc* d, std::sha
             const uint32_t mfl = (md.has_normals ? YK_MESH_NORMALS : 0u) | (md.has_uvs ? YK_MESH_UVS : 0u) | (md.swaps_handedness ? YK_MESH_SWAPS : 0u);
             prim_shade[p] = make_uint4(d->indices[3 * src], d->indices[3 * src + 1], d->indices[3 * src + 2],
                                        ((uint32_t)d->tri_material[src] << 6) | (mat_kind[d->tri_material[src]] << 3) | mfl);
+        }
+        if (d->normals || d->uvs) {  // leaf-order copy of the per-vertex normals / uvs (yk_device.h: DevScene::prim_attr)
+            s->prim_attr.assign(4 * np, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            for (size_t p = 0; p < np; ++p) {
+                const uint32_t src = bvh->shape_order[p];
+                if (src >= d->n_triangles) continue;
+                const yk_mesh_desc& md = d->meshes[d->tri_mesh ? d->tri_mesh[src] : 0];
+                float nrm[3][3] = {}, uv[3][2] = {};
+                for (int k = 0; k < 3; ++k) {
+                    const size_t vi = d->indices[3 * (size_t)src + k];
+                    if (md.has_normals)
+                        for (int c = 0; c < 3; ++c) nrm[k][c] = d->normals[3 * vi + c];
+                    if (md.has_uvs)
+                        for (int c = 0; c < 2; ++c) uv[k][c] = d->uvs[2 * vi + c];
+                }
+                s->prim_attr[4 * p + 0] = make_float4(nrm[0][0], nrm[0][1], nrm[0][2], uv[0][0]);
+                s->prim_attr[4 * p + 1] = make_float4(nrm[1][0], nrm[1][1], nrm[1][2], uv[0][1]);
+                s->prim_attr[4 * p + 2] = make_float4(nrm[2][0], nrm[2][1], nrm[2][2], uv[1][0]);
+                s->prim_attr[4 * p + 3] = make_float4(uv[1][1], uv[2][0], uv[2][1], 0.0f);
+            }
         }
         std::vector<uint32_t>& mesh_flags = s->mesh_flags;
         mesh_flags.assign(std::max<uint32_t>(d->n_meshes, 1), 0);
@@ -682,6 +702,7 @@ yk_status yk_upload_scene_image(yk_context* ctx, const std::shared_ptr<SceneImag
         UP(top_nodes, img->top.data(), img->top.size());
         UP(tris, img->tris.data(), img->tris.size());
         UP(prim_shade, img->prim_shade.data(), img->prim_shade.size());
+        UP(prim_attr, img->prim_attr.data(), img->prim_attr.size());
         UP(indices, d->indices, 3 * (size_t)d->n_triangles);
         UP(points, d->points, 3 * (size_t)d->n_vertices);
         UP(normals, d->normals, d->normals ? 3 * (size_t)d->n_vertices : 0);
@@ -705,6 +726,7 @@ yk_status yk_upload_scene_image(yk_context* ctx, const std::shared_ptr<SceneImag
         ds.n_top = (uint32_t)img->top.size();
         ds.tris = s->tris.as<float4>();
         ds.prim_shade = s->prim_shade.as<uint4>();
+        ds.prim_attr = img->prim_attr.empty() ? nullptr : s->prim_attr.as<float4>();
         ds.spheres = d->n_spheres ? s->spheres.as<DevSphere>() : nullptr;
         ds.n_triangles = d->n_triangles;
         ds.root_ref = img->root_ref;
@@ -728,7 +750,7 @@ yk_status yk_upload_scene_image(yk_context* ctx, const std::shared_ptr<SceneImag
         ds.tex_info = d->n_textures ? s->tex_info.as<uint4>() : nullptr;
         s->on_device = true;
         s->info.upload_seconds = now_seconds() - u0;
-        DevBuf* all[] = {&s->nodes, &s->nodes4, &s->top_nodes, &s->tris, &s->prim_shade, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
+        DevBuf* all[] = {&s->nodes, &s->nodes4, &s->top_nodes, &s->tris, &s->prim_shade, &s->prim_attr, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
                          &s->mesh_flags, &s->materials, &s->lights, &s->spheres, &s->texels, &s->tex_info};
         for (DevBuf* b : all) s->info.device_bytes += b->bytes;
     }
@@ -754,7 +776,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
 void yk_scene_destroy(yk_scene* s) {
     if (!s) return;
     if (s->device >= 0) (void)hipSetDevice(s->device);
-    DevBuf* all[] = {&s->nodes, &s->nodes4, &s->top_nodes, &s->tris, &s->prim_shade, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
+    DevBuf* all[] = {&s->nodes, &s->nodes4, &s->top_nodes, &s->tris, &s->prim_shade, &s->prim_attr, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
                      &s->mesh_flags, &s->materials, &s->lights, &s->spheres, &s->texels, &s->tex_info};
     for (DevBuf* b : all) b->release();
     delete s;
@@ -909,7 +931,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
     // scheduler even out the iterations' very different costs; 8 persistent-style blocks per CU were 2.9 % slower
     // on the frame (sweep 3..1024: 147.3, 146.9, 148.0 (8), 146.6, 145.4 (24), 145.1 (96), 143.7 (256), 144.2, 144.3 ms)
     static const unsigned shade_bpc = std::getenv("YK_SHADE_BPC") ? (unsigned)std::atoi(std::getenv("YK_SHADE_BPC")) : 256u;
-    const unsigned sg = fit((unsigned)ctx->n_cu * shade_bpc, n_paths);
+    const unsigned sg = fit((unsigned)ctx->n_cu * shade_bpc, n_paths);  // k_accumulate: 256 paths per block and step
     const unsigned spill_stride = trace_grid(ctx) * trace_block_size();
     unsigned cur = 0;
     // Bounce b: trace_closest -> shade on `st`; then {trace_any, accumulate}(b) go to the side
@@ -941,7 +963,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         e = kt.begin(st);
         launch_shade(st, sg, ds, prm, pixel_xy, sample_index_tab, pc, pn, ws.hit.as<int>(), ws.pend.as<float4>(), ws.shO.as<float4>(),
                      ws.shD.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ws.shq.as<unsigned>(), ws.shO2.as<float4>(),
-                     ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc, split ? 1u : 0u, (b > 0 && ctx->shade_reorder) ? 1u : 0u);
+                     ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc, split ? 1u : 0u, (b > 0 && ctx->shade_reorder) ? 1u : 0u, 3u * (unsigned)ctx->n_cu);
         kt.end(e, 2, st);
         if (overlap) {
             (void)hipEventRecord(ws.ev_shade, st);

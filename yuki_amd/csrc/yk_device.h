@@ -87,9 +87,15 @@ struct DevSphere {
     unsigned pad;
 };
 
-// primitive flag bits in tris[3p+2].w
+// primitive flag bits in tris[3p+2].w; bits 4-6: the primitive's BSDF kind (MK_*), which the render-loop traversal
+// kernels copy into the hit word so that k_shade can sort a block's paths by kind without a dependent fetch
 #define YK_PRIM_LAST 1u
 #define YK_PRIM_SPHERE 2u
+#define YK_PRIM_KIND_SHIFT 4
+// hit[i] of the render loop: -1 = miss, else leaf-order slot (< 2^28, YK_REF_INDEX_MAX) | BSDF kind << 28
+#define YK_HIT_KIND_SHIFT 28
+#define YK_HIT_PRIM_MASK 0x0fffffffu
+#define YK_HIT_WORD(prim, pflags) ((int)((prim) | ((((pflags) >> YK_PRIM_KIND_SHIFT) & 7u) << YK_HIT_KIND_SHIFT)))
 
 // mesh flag bits
 #define YK_MESH_NORMALS 1u
@@ -103,6 +109,9 @@ struct DevScene {
     uint32_t n_top;
     const float4* tris;  // 3 per primitive in leaf order: (p0, bits(area_light)) (p1, bits(source shape)) (p2, bits(YK_PRIM_*))
     const uint4* prim_shade;   // per primitive in leaf order: (i0, i1, i2, material << 6 | material kind (MK_*) << 3 | YK_MESH_* flags)
+    // per primitive in leaf order, 4 x float4: (n0, uv0.x) (n1, uv0.y) (n2, uv1.x) (uv1.y, uv2.x, uv2.y, 0) — the vertex normals and uvs
+    // k_shade needs, addressed by the hit alone; null when no mesh has normals or uvs
+    const float4* prim_attr;
     const DevSphere* spheres;  // source shape s >= n_triangles is spheres[s - n_triangles]
     uint32_t n_triangles;
     uint32_t root_ref;

@@ -191,14 +191,18 @@ YK_HD Surface make_surface_sphere(const DevSphere& sp, V3 ro, V3 rd, float t, V3
     return s;
 }
 
-// SurfaceInteraction of a triangle hit from its vertices (world space), vertex indices (for
-// the per-vertex normals / uvs) and mesh flags
-YK_HD Surface make_surface_core(const DevScene& sc, V3 p0, V3 p1, V3 p2, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t mflags, const TriHit& h) {
+// SurfaceInteraction of a triangle hit from its vertices (world space), the per-vertex uvs and normals of the mesh
+// (read only when the mesh flags say they exist) and the mesh flags: triangle.rs:141-226 + interaction.rs:95-132
+struct TriAttr {
+    float u0x, u0y, u1x, u1y, u2x, u2y;
+    V3 n0, n1, n2;
+};
+YK_HD Surface make_surface_vals(V3 p0, V3 p1, V3 p2, const TriAttr& at, uint32_t mflags, const TriHit& h) {
     float u0x = 0.0f, u0y = 0.0f, u1x = 1.0f, u1y = 0.0f, u2x = 1.0f, u2y = 1.0f;  // triangle.rs:143-149
     if (mflags & YK_MESH_UVS) {
-        u0x = sc.uvs[2 * i0]; u0y = sc.uvs[2 * i0 + 1];
-        u1x = sc.uvs[2 * i1]; u1y = sc.uvs[2 * i1 + 1];
-        u2x = sc.uvs[2 * i2]; u2y = sc.uvs[2 * i2 + 1];
+        u0x = at.u0x; u0y = at.u0y;
+        u1x = at.u1x; u1y = at.u1y;
+        u2x = at.u2x; u2y = at.u2y;
     }
     float duv02x = u0x - u2x, duv02y = u0y - u2y;
     float duv12x = u1x - u2x, duv12y = u1y - u2y;
@@ -224,7 +228,7 @@ YK_HD Surface make_surface_core(const DevScene& sc, V3 p0, V3 p1, V3 p2, uint32_
     s.ns = n;
     s.dpdus = dpdu;
     if (mflags & YK_MESH_NORMALS) {
-        V3 n0 = ld3(sc.normals, i0), n1 = ld3(sc.normals, i1), n2 = ld3(sc.normals, i2);
+        V3 n0 = at.n0, n1 = at.n1, n2 = at.n2;
         V3 ns;
         V3 nn = normalize(n0 * h.b0 + n1 * h.b1 + n2 * h.b2);
         if (len_sqr(nn) > 0.0f)
@@ -247,6 +251,24 @@ YK_HD Surface make_surface_core(const DevScene& sc, V3 p0, V3 p1, V3 p2, uint32_
     s.material = 0;
     s.area_light = -1;
     return s;
+}
+
+// the same through the vertex indices (per-vertex arrays of the scene description)
+YK_HD Surface make_surface_core(const DevScene& sc, V3 p0, V3 p1, V3 p2, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t mflags, const TriHit& h) {
+    TriAttr at;
+    at.u0x = at.u0y = at.u1x = at.u1y = at.u2x = at.u2y = 0.0f;
+    at.n0 = at.n1 = at.n2 = V3{0.0f, 0.0f, 0.0f};
+    if (mflags & YK_MESH_UVS) {
+        at.u0x = sc.uvs[2 * i0]; at.u0y = sc.uvs[2 * i0 + 1];
+        at.u1x = sc.uvs[2 * i1]; at.u1y = sc.uvs[2 * i1 + 1];
+        at.u2x = sc.uvs[2 * i2]; at.u2y = sc.uvs[2 * i2 + 1];
+    }
+    if (mflags & YK_MESH_NORMALS) {
+        at.n0 = ld3(sc.normals, i0);
+        at.n1 = ld3(sc.normals, i1);
+        at.n2 = ld3(sc.normals, i2);
+    }
+    return make_surface_vals(p0, p1, p2, at, mflags, h);
 }
 
 YK_HD Surface make_surface(const DevScene& sc, uint32_t tri, const TriHit& h) {
@@ -291,11 +313,26 @@ YK_HD Surface hit_surface_prim(const DevScene& sc, uint32_t prim, V3 o, V3 d) {
         sphere_hit_t(sp, o, d, __builtin_inff(), t, ro, rd);
         return make_surface_sphere(sp, ro, rd, t, d, sc.texels != nullptr);
     }
+    // per-vertex normals and uvs of the primitive, copied into leaf order at scene creation: their address depends on the
+    // hit alone, so they are in flight together with the vertices instead of waiting for the vertex indices (k_shade
+    // of an incoherent bounce is a chain of dependent gathers at three waves per SIMD; this removes one link)
+    TriAttr at;
+    at.u0x = at.u0y = at.u1x = at.u1y = at.u2x = at.u2y = 0.0f;
+    at.n0 = at.n1 = at.n2 = V3{0.0f, 0.0f, 0.0f};
+    if (sc.prim_attr && (ps.w & (YK_MESH_NORMALS | YK_MESH_UVS))) {
+        const float4 a0 = sc.prim_attr[4 * (size_t)prim], a1 = sc.prim_attr[4 * (size_t)prim + 1], a2 = sc.prim_attr[4 * (size_t)prim + 2], a3 = sc.prim_attr[4 * (size_t)prim + 3];
+        at.n0 = V3{a0.x, a0.y, a0.z};
+        at.n1 = V3{a1.x, a1.y, a1.z};
+        at.n2 = V3{a2.x, a2.y, a2.z};
+        at.u0x = a0.w; at.u0y = a1.w;
+        at.u1x = a2.w; at.u1y = a3.x;
+        at.u2x = a3.y; at.u2y = a3.z;
+    }
     RayTri rt = ray_tri_setup(d);
     TriHit th = TriHit{0.0f, 0.0f, 0.0f, 0.0f};
     const V3 p0 = V3{v0.x, v0.y, v0.z}, p1 = V3{v1.x, v1.y, v1.z}, p2 = V3{v2.x, v2.y, v2.z};
     tri_intersect(o, rt, __builtin_inff(), p0, p1, p2, th);
-    Surface s = make_surface_core(sc, p0, p1, p2, ps.x, ps.y, ps.z, ps.w & 7u, th);
+    Surface s = sc.prim_attr ? make_surface_vals(p0, p1, p2, at, ps.w & 7u, th) : make_surface_core(sc, p0, p1, p2, ps.x, ps.y, ps.z, ps.w & 7u, th);
     s.material = (int)(ps.w >> 6);
     s.area_light = (int)__float_as_uint(v0.w);
     s.wo = -d;

@@ -108,10 +108,14 @@ __global__ void k_raygen_user(RenderParams prm, const float* ray_o, const float*
 // "dequeue") and made this kernel atomic-bound (profiles/r01_a_*: 0.178 s/frame,
 // 79 % of wave cycles waiting).
 #ifndef SHADE_CAP
-#define SHADE_CAP 384  // staged continuation paths per block (64 B each)
+#define SHADE_CAP 336  // staged continuation paths per block (64 B each).  With SHADE_CAPQ and the sort window's order table the block's LDS is
+                       // 53296 B: three blocks per CU (LDS is handed out in 1280-byte granules on gfx950: 53760 x 3 fits 160 KB, one granule more does not)
 #endif
 #ifndef SHADE_CAPQ
 #define SHADE_CAPQ 768  // staged shadow rays per block (36 B each): a whole iteration of 256 paths x 3 lights fits
+#endif
+#ifndef SHADE_WIN
+#define SHADE_WIN 8  // at most this many iterations (of 256 paths) are sorted by material kind together (the launch passes the actual number)
 #endif
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (blocks of 256 threads)
@@ -123,8 +127,8 @@ template <int CAP, int CAPQ> struct ShadeStaging {
     unsigned qS[CAPQ];
     unsigned fill_p, fill_q, gbase;
     unsigned q_delta;  // class of the staged shadow rays: 1 = towards a point/spot/distant light
-    unsigned bucket[8];          // material-kind histogram of the iteration's 256 paths
-    unsigned short order[256];   // sorted position -> lane whose path it is
+    unsigned bucket[8];                  // material-kind histogram of the window's paths
+    unsigned short order[SHADE_WIN * 256];  // sorted position -> offset of the path inside the window
 };
 
 // every thread of the block calls this (converged); returns the staging position
@@ -140,12 +144,27 @@ __device__ __forceinline__ unsigned block_append(bool want, unsigned* lds_fill) 
 
 __device__ __forceinline__ unsigned valid_light_kind(const DevScene& sc, unsigned l) { return sc.lights[l].kind; }
 
+// Diagnostic builds only (tools/build_variant.sh prof -DYK_SHADE_PROFILE): per-wave cycle stamps around the stages of an
+// iteration, summed into a device array (tools/micro/shade_profile.h).  The product build sees empty macros.
+#ifdef YK_SHADE_PROFILE
+#include "../../tools/micro/shade_profile.h"
+#else
+#define YK_PROF_DECL
+#define YK_PROF_STAMP(k)
+#define YK_PROF_FLUSH
+#endif
+
 template <int BLOCK, int CAP, int CAPQ>
 __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                                                  PathBuffers cur, PathBuffers nxt,
                                                  const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis,
-                                                 unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder) {
+                                                 unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder,
+                                                 unsigned win_max, unsigned block_slots) {
     // `bc`: this bounce's words of the control block (yk_device.h); the next bounce's follow it
+    // iterations per window: a full queue sorts win_max (<= SHADE_WIN) x 256 paths together; a queue too short to give every
+    // resident block (`block_slots` of them on the device) a full window takes shorter ones, down to one iteration
+    const unsigned win_iters = min(win_max, max(1u, bc[0] / (BLOCK * block_slots)));
+    static_assert(sizeof(ShadeStaging<CAP, CAPQ>) <= 53760, "k_shade: more than 42 LDS granules per block costs the third block per CU");
     __shared__ ShadeStaging<CAP, CAPQ> stg;
     const unsigned n = bc[0];
     const unsigned nl = sc.n_lights;
@@ -197,29 +216,66 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
     // of the per-light decisions cost more than the math between them).
     const bool per_iter = !split_delta && BLOCK * nl <= (unsigned)CAPQ;
     // all lanes stay in the loop together so the ballots below see whole waves
-    const unsigned n_round = (n + BLOCK - 1) / BLOCK * BLOCK;
-    for (unsigned i0 = blockIdx.x * BLOCK + threadIdx.x; i0 < n_round; i0 += gridDim.x * BLOCK) {
-        unsigned i = i0;
-        if (reorder) {
-            // After the first bounce the 64 paths of a wave hit surfaces of five material kinds and
-            // every wave runs every kind's BSDF code (measured: 166 ps per path against 110 ps when all
-            // materials are one Lambert).  The block's 256 paths are therefore dealt to the lanes
-            // sorted by the material kind of what they hit: a wave sees one or two kinds.  Which lane
-            // shades which path has no influence on any result.
-            const int t = i0 < n ? hit_tri[i0] : -1;
-            const unsigned key = i0 >= n ? 7u : (t < 0 ? 6u : ((sc.prim_shade[t].w >> 3) & 7u));
-            if (threadIdx.x < 8) stg.bucket[threadIdx.x] = 0;
-            __syncthreads();
-            const unsigned rank = atomicAdd(&stg.bucket[key], 1u);
-            __syncthreads();
-            unsigned base = 0;
-            for (unsigned k = 0; k < key; ++k) base += stg.bucket[k];
-            stg.order[base + rank] = (unsigned short)threadIdx.x;
-            __syncthreads();
-            i = (i0 - threadIdx.x) + stg.order[threadIdx.x];
+    const unsigned WIN = win_iters * BLOCK;  // paths per window
+    const unsigned n_win = (n + WIN - 1) / WIN;
+    YK_PROF_DECL
+    for (unsigned w = blockIdx.x; w < n_win; w += gridDim.x) {
+      const unsigned wbase = w * WIN;
+      unsigned n_sub = win_iters;
+      YK_PROF_STAMP(0)
+      if (reorder) {
+        // After the first bounce the 64 paths of a wave hit surfaces of five material kinds and every wave runs every
+        // kind's BSDF code (PMC: 3750 VALU instructions per wave and vertex at 55 % lane utilisation against 2740 at
+        // 91 % for the camera rays' vertices).  The paths of a window — SHADE_WIN iterations of the block — are therefore
+        // dealt to the lanes sorted by the material kind of what they hit (the traversal kernel left the kind in the hit
+        // word): with 4 x 256 paths and six keys most waves see ONE kind.  Which lane shades which path has no
+        // influence on any result.  Counting sort: per key one ballot per wave and one LDS atomic per wave and key.
+        if (threadIdx.x < 8) stg.bucket[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned key[SHADE_WIN], rank[SHADE_WIN];
+#pragma unroll
+        for (int k = 0; k < SHADE_WIN; ++k) {
+            const unsigned i0 = wbase + k * BLOCK + threadIdx.x;
+            const bool in = (unsigned)k < win_iters && i0 < n;
+            const int t = in ? hit_tri[i0] : -1;
+            key[k] = !in ? 7u : (t < 0 ? 6u : ((unsigned)t >> YK_HIT_KIND_SHIFT));
         }
+#pragma unroll
+        for (int k = 0; k < SHADE_WIN; ++k) {
+            rank[k] = 0;
+            if ((unsigned)k >= win_iters) continue;  // block-uniform
+            for (unsigned q = 0; q < 8; ++q) {  // wave-uniform loop: every lane takes part in every ballot
+                const unsigned long long m = __ballot(key[k] == q);
+                if (m == 0ull) continue;
+                unsigned b0 = 0;
+                if (lane_id() == 0) b0 = atomicAdd(&stg.bucket[q], (unsigned)__popcll(m));
+                b0 = __shfl(b0, 0);
+                if (key[k] == q) rank[k] = b0 + (unsigned)__popcll(m & ((1ull << lane_id()) - 1ull));
+            }
+        }
+        __syncthreads();
+        unsigned first[8];
+        {
+            unsigned acc = 0;
+            for (unsigned q = 0; q < 8; ++q) {
+                first[q] = acc;
+                acc += stg.bucket[q];
+            }
+            n_sub = (acc - stg.bucket[7] + BLOCK - 1) / BLOCK;  // the invalid entries sort last: trailing iterations without any path are skipped
+        }
+#pragma unroll
+        for (int k = 0; k < SHADE_WIN; ++k)
+            if ((unsigned)k < win_iters) stg.order[first[key[k]] + rank[k]] = (unsigned short)(k * BLOCK + threadIdx.x);
+        __syncthreads();
+      } else {
+        const unsigned left = n - wbase;  // w < n_win: at least one path
+        n_sub = left >= WIN ? win_iters : (left + BLOCK - 1) / BLOCK;
+      }
+      for (unsigned sub = 0; sub < n_sub; ++sub) {
+        const unsigned i = wbase + (reorder ? (unsigned)stg.order[sub * BLOCK + threadIdx.x] : sub * BLOCK + threadIdx.x);
         const bool valid = i < n;
         bool alive = false;
+        YK_PROF_STAMP(1)
         if (per_iter) {
             // ONE block-wide decision per iteration: room for every shadow ray (BLOCK x nl) and every
             // continuation (BLOCK) this iteration can stage, so the appends below need no barriers
@@ -268,8 +324,9 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
             st.sample_index = (sample_index_tab ? sample_index_tab[pix] : 0u) + sid % prm.spe;
             int tri = hit_tri[i];
             hit = tri >= 0;
-            if (hit) vertex_setup(sc, (uint32_t)tri, o, d, v);  // `tri` is the leaf-order slot reported by the render-loop trace kernels
+            if (hit) vertex_setup(sc, (uint32_t)tri & YK_HIT_PRIM_MASK, o, d, v);  // the leaf-order slot reported by the render-loop trace kernels
         }
+        YK_PROF_STAMP(2)
         // ---- next-event estimation over ALL lights (path.rs:102-119); two sampler
         // dimensions are consumed per light whether or not it contributes.
         for (unsigned l = 0; l < nl; ++l) {
@@ -301,6 +358,7 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
                 shC[slot] = make_float4(ne.contrib.r, ne.contrib.g, ne.contrib.b, 0.0f);
             }
         }
+        YK_PROF_STAMP(3)
         if (valid) {
             unsigned kind = 0;
             RGB term = RGB{0, 0, 0};
@@ -321,6 +379,7 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
             }
             pend[i] = make_float4(term.r, term.g, term.b, __uint_as_float(kind));
         }
+        YK_PROF_STAMP(4)
         // ---- stream compaction of the survivors into the other buffer
         if (!per_iter) {
             __syncthreads();
@@ -335,7 +394,11 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
             stg.pT[j] = nT;
             stg.pR[j] = nR;
         }
+        YK_PROF_STAMP(5)
+      }
+      if (reorder) __syncthreads();  // the next window's sort overwrites `order`
     }
+    YK_PROF_FLUSH
     __syncthreads();
     {
         const unsigned fq = stg.fill_q, fp = stg.fill_p;
@@ -455,7 +518,7 @@ __global__ void k_debug_shade(DevScene sc, uint32_t integrator, PathBuffers cur,
         c = RGB{(float)s.x, (float)s.y, tri >= 0 ? (float)s.y : 0.0f};
     } else if (tri >= 0) {
         V3 o = f4_xyz(cur.rayO[i]), d = f4_xyz(cur.rayD[i]);
-        Surface sf = hit_surface_prim(sc, (uint32_t)tri, o, d);  // the normals integrators trace with the render-loop kernel: leaf-order slots
+        Surface sf = hit_surface_prim(sc, (uint32_t)tri & YK_HIT_PRIM_MASK, o, d);  // the normals integrators trace with the render-loop kernel: leaf-order slots
         V3 nn = integrator == YK_INTEGRATOR_GEOMETRY_NORMALS ? sf.n : sf.ns;
         c = RGB{nn.x, nn.y, nn.z} / 2.0f + 0.5f;
     }
@@ -571,6 +634,18 @@ __global__ void k_unpack_rays(size_t n, const float4* rayO, const float4* rayD, 
     d[3 * i] = b.x; d[3 * i + 1] = b.y; d[3 * i + 2] = b.z;
 }
 
+#ifdef YK_SHADE_PROFILE
+}  // namespace yk
+extern "C" int yk_debug_shade_profile(unsigned long long* out8, int reset) {
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipDeviceSynchronize();
+    int rc = (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(yk::yk_shade_prof), sizeof(zero));
+    if (reset) rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(yk::yk_shade_prof), zero, sizeof(zero));
+    return rc;
+}
+namespace yk {
+#endif
+
 // ------------------------------------------------------------------ launchers
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
@@ -592,9 +667,9 @@ void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, 
 void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                   PathBuffers cur, PathBuffers nxt,
                   const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis, unsigned* shq, float4* shO2,
-                  float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder) {
+                  float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder, unsigned block_slots) {
     hipLaunchKernelGGL((k_shade<256, SHADE_CAP, SHADE_CAPQ>), dim3(grid), dim3(256), 0, s, sc, prm, pixel_xy, sample_index_tab, cur, nxt, hit_tri, pend, shO, shD, shC, vis, shq,
-                       shO2, shD2, shq2, bc, split_delta, reorder);
+                       shO2, shD2, shq2, bc, split_delta, reorder, (unsigned)SHADE_WIN, block_slots);
 }
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
                        const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* bc) {

@@ -129,7 +129,7 @@ __device__ __forceinline__ void pkt_closest_group(const DevScene& sc, PktStack& 
                         got = tri_intersect(r.o, r.rt, r.t_max, f4_xyz(v0), f4_xyz(v1), f4_xyz(v2), h);
                     }
                     if (got) {
-                        best = (int)prim;  // leaf-order slot, like the render-loop flavour of k_trace_closest_pt
+                        best = YK_HIT_WORD(prim, pflags);  // leaf-order slot | BSDF kind, like the render-loop flavour of k_trace_closest_pt
                         r.t_max = h.t;
                     }
                 }

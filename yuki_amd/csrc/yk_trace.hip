@@ -514,7 +514,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(Dev
                     if (API) best_hit = h;
                     // API callers get the source shape; the render loop gets the leaf-order slot, from
                     // which k_shade reaches everything it needs in one hop (hit_surface_prim)
-                    best = API ? (int)__float_as_uint(v1.w) : (int)prim;
+                    best = API ? (int)__float_as_uint(v1.w) : YK_HIT_WORD(prim, pflags);
                     r.t_max = h.t;
                 }
                 if (pflags & YK_PRIM_LAST) break;
