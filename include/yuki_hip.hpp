@@ -214,4 +214,52 @@ class Integrator {
     yk_integrator_desc desc_;
 };
 
+// All GPUs of the process behind one object — RenderManager's role for GPU workers
+// (renderer/render_manager.rs:78-97: one worker per device; :206-210: interleaved tiles;
+// film.rs:210-282: the write-back).  devices[0] assembles the film.
+class Node {
+   public:
+    explicit Node(const std::vector<int>& devices) { check(yk_multi_create(devices.data(), (uint32_t)devices.size(), &m_)); }
+    ~Node() {
+        if (film_) yk_multi_film_destroy(film_);
+        if (scene_) yk_multi_scene_destroy(scene_);
+        if (m_) yk_multi_destroy(m_);
+    }
+    Node(const Node&) = delete;
+    Node& operator=(const Node&) = delete;
+    uint32_t device_count() const { return yk_multi_device_count(m_); }
+    void set_option(const char* key, int64_t value) { mcheck(yk_multi_set_option(m_, key, value)); }
+    // BoundingVolumeHierarchy::new once, one copy per device
+    void set_scene(const yk_scene_desc& d) {
+        if (scene_) yk_multi_scene_destroy(scene_);
+        scene_ = nullptr;
+        mcheck(yk_multi_scene_create(m_, &d, &scene_));
+    }
+    void set_film(const FilmSettings& fs) {
+        if (film_) yk_multi_film_destroy(film_);
+        film_ = nullptr;
+        fs_ = fs;
+        mcheck(yk_multi_film_create(m_, fs.res_x, fs.res_y, fs.tile_dim, &film_));
+    }
+    // every tile of the film on its device, the exchange, Film::update_tile: row-major RGB, res_x * res_y * 3 floats
+    yk_render_stats render_film(const Camera& camera, const yk_sampler_desc& sampler, const yk_integrator_desc& integrator, float* film_rgb, yk_cancel_fn cancel = nullptr,
+                                void* user = nullptr) {
+        yk_render_stats st{};
+        mcheck(yk_multi_render_film(m_, scene_, &camera.matrices, &sampler, &integrator, film_, film_rgb, &st, cancel, user));
+        return st;
+    }
+
+   private:
+    void mcheck(yk_status s) const {
+        if (s == YK_OK) return;
+        char buf[512] = {0};
+        yk_multi_last_error(m_, buf, sizeof(buf));
+        throw Error(s, std::string(yk_status_string(s)) + (buf[0] ? std::string(": ") + buf : std::string()));
+    }
+    yk_multi* m_ = nullptr;
+    yk_multi_scene* scene_ = nullptr;
+    yk_multi_film* film_ = nullptr;
+    FilmSettings fs_;
+};
+
 }  // namespace yuki

@@ -111,6 +111,25 @@ int main(int argc, char** argv) {
         for (size_t k = 0; k < acc.size(); ++k) eq = eq && (acc[k] / 4.0f == film[k]);
         std::printf("accumulate_matches_plain=%d\n", eq ? 1 : 0);
     }
+    // the GPUs of the process behind one object (here: device 0, the RCCL exchange looped back to itself): the film
+    // equals Film::update_tile of the batched render above
+    {
+        Node node({0});
+        node.set_option("rccl_loopback", 1);
+        node.set_scene(d);
+        node.set_film(fs);
+        std::vector<float> whole((size_t)fs.res_x * fs.res_y * 3), ref(whole.size());
+        yk_render_stats ms = node.render_film(cam, smp, IntegratorType::Path(PathParams{6, false, 0.0f}), whole.data());
+        yk_film_update_tiles(tiles.data(), tiles.size(), film.data(), fs.res_x, fs.res_y, ref.data());
+        std::printf("node_rays_match=%d node_film_matches=%d node_devices=%u\n", ms.rays == st.rays ? 1 : 0, std::memcmp(whole.data(), ref.data(), whole.size() * 4) == 0 ? 1 : 0,
+                    node.device_count());
+        try {
+            Node two({0, 0});
+            std::printf("node_dup=accepted\n");
+        } catch (const Error& e) {
+            std::printf("node_dup=status%d\n", (int)e.status);
+        }
+    }
     try {
         FilmTile bad{8, 8, 8, 12};
         path.render(scene, cam, smp, bad, tile_px.data());

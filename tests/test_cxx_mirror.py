@@ -57,3 +57,4 @@ def test_cxx_mirror_renders(tmp_path):
     assert kv["tile_matches_batch"] == "1" and int(kv["tile_rays"]) > 0
     assert kv["bad_tile"] == "status1"
     assert kv["accumulate_matches_plain"] == "1"
+    assert kv["node_rays_match"] == "1" and kv["node_film_matches"] == "1" and kv["node_devices"] == "1" and kv["node_dup"] == "status1"

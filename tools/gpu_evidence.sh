@@ -1,8 +1,8 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd $R
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/r02_pytest_gpu_3.log 2>&1 || { tail -40 $O/r02_pytest_gpu_3.log; exit 1; }
-tail -2 $O/r02_pytest_gpu_3.log
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/r02_pytest_gpu_final.log 2>&1 || { tail -40 $O/r02_pytest_gpu_final.log; exit 1; }
+tail -2 $O/r02_pytest_gpu_final.log
 bash tools/profile_round.sh r02_a cfg3
 cp $O/r02_a_pmc_cfg3.json profiles/
 python3 bench.py --steps 5 > $O/r02_a_bench.json 2> $O/r02_a_bench.log
