@@ -202,6 +202,10 @@ def main():
             os.environ.setdefault("WORLD_SIZE", "1")
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # one node: the out-of-band sockets of gloo and of RCCL's bootstrap can use the loopback interface, which exists
+        # and resolves everywhere (the container's hostname may not); GPU-to-GPU data does not travel over it
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         if args.rehearse_on_one_gpu:
             local_rank = 0
             torch.cuda.set_device(0)

@@ -6,6 +6,7 @@ import ctypes as C
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  first: this process then holds ONE RCCL, PyTorch's — libyuki_hip.so binds the loaded copy (yk_multi.cpp)
 
 from yuki_amd import scenes
 

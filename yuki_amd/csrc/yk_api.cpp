@@ -326,7 +326,7 @@ struct SceneImage {
     yk_scene_info info;  // host part: node counts, bounds, build time
     bool has_device_records = false, wide = false, wide_auto = false;
     uint32_t root_ref = 0;
-    std::vector<DevNode> dn, top;
+    std::vector<DevNode> dn, top, top_any;
     std::vector<DevNode4> dn4;
     std::vector<float4> tris, texels, prim_attr;
     std::vector<uint4> prim_shade, tex_info;
@@ -475,14 +475,16 @@ yk_status yk_build_scene_image(yk_context* ctx, const yk_scene_desc* d, std::sha
             o.q2 = make_float4(c1.bmin[2], c1.bmax[0], c1.bmax[1], c1.bmax[2]);
             o.q3 = make_uint4(ref_of((uint32_t)i + 1), ref_of(nodes[i].a) | ((uint32_t)nodes[i].axis << YK_AXIS_SHIFT), 0u, 0u);
         }
-        // top of the tree, breadth first, for the LDS-resident copy (YK_TOP_BIT refs)
-        std::vector<DevNode>& top = s->top;
-        if (!nodes[0].is_leaf && ctx->top_nodes > 0) {
+        // top of the tree, breadth first, for the LDS-resident copies (YK_TOP_BIT refs).  Two sets: the closest-hit kernels
+        // keep 8-byte stack entries (ref, entry distance) in LDS and have room for trace_top_nodes() nodes beside them; the
+        // any-hit kernel's entries are a bare ref (4 bytes), which leaves room for trace_top_nodes_any() — more than twice as many.
+        auto build_top = [&](size_t cap, std::vector<DevNode>& top) {
+            top.clear();
+            if (nodes[0].is_leaf || cap == 0) return;
             std::vector<uint32_t> order;  // reference node indices, breadth first
             std::vector<uint32_t> top_id(nodes.size(), 0xffffffffu);
             order.push_back(0);
             top_id[0] = 0;
-            const size_t cap = (size_t)std::min<int64_t>(ctx->top_nodes, trace_top_nodes());
             for (size_t q = 0; q < order.size() && order.size() < cap; ++q) {
                 const uint32_t P = order[q];
                 for (uint32_t c : {P + 1, nodes[P].a}) {
@@ -499,7 +501,10 @@ yk_status yk_build_scene_image(yk_context* ctx, const yk_scene_desc* d, std::sha
                 if (top_id[c1] != 0xffffffffu) t.q3.y = YK_TOP_BIT | top_id[c1] | ((uint32_t)nodes[P].axis << YK_AXIS_SHIFT);
                 top.push_back(t);
             }
-        }
+        };
+        std::vector<DevNode>& top = s->top;
+        build_top((size_t)std::min<int64_t>(ctx->top_nodes, trace_top_nodes()), s->top);
+        build_top((size_t)std::min<int64_t>(ctx->top_nodes, trace_top_nodes_any()), s->top_any);
         // 4-wide collapse (DevNode4): one node per reference interior node reached at even depth
         // below the root.  Built only while the traversal stack of the collapsed tree is
         // guaranteed to fit (the reference asserts on its own stack depth, bvh.rs:172-174).
@@ -700,6 +705,7 @@ yk_status yk_upload_scene_image(yk_context* ctx, const std::shared_ptr<SceneImag
         UP(nodes, img->dn.data(), img->dn.size());
         UP(nodes4, img->dn4.data(), img->dn4.size());
         UP(top_nodes, img->top.data(), img->top.size());
+        UP(top_nodes_any, img->top_any.data(), img->top_any.size());
         UP(tris, img->tris.data(), img->tris.size());
         UP(prim_shade, img->prim_shade.data(), img->prim_shade.size());
         UP(prim_attr, img->prim_attr.data(), img->prim_attr.size());
@@ -724,6 +730,8 @@ yk_status yk_upload_scene_image(yk_context* ctx, const std::shared_ptr<SceneImag
         s->wide_auto = img->wide_auto;
         ds.top_nodes = s->top_nodes.as<DevNode>();
         ds.n_top = (uint32_t)img->top.size();
+        ds.top_nodes_any = s->top_nodes_any.as<DevNode>();
+        ds.n_top_any = (uint32_t)img->top_any.size();
         ds.tris = s->tris.as<float4>();
         ds.prim_shade = s->prim_shade.as<uint4>();
         ds.prim_attr = img->prim_attr.empty() ? nullptr : s->prim_attr.as<float4>();
@@ -750,7 +758,7 @@ yk_status yk_upload_scene_image(yk_context* ctx, const std::shared_ptr<SceneImag
         ds.tex_info = d->n_textures ? s->tex_info.as<uint4>() : nullptr;
         s->on_device = true;
         s->info.upload_seconds = now_seconds() - u0;
-        DevBuf* all[] = {&s->nodes, &s->nodes4, &s->top_nodes, &s->tris, &s->prim_shade, &s->prim_attr, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
+        DevBuf* all[] = {&s->nodes, &s->nodes4, &s->top_nodes, &s->top_nodes_any, &s->tris, &s->prim_shade, &s->prim_attr, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
                          &s->mesh_flags, &s->materials, &s->lights, &s->spheres, &s->texels, &s->tex_info};
         for (DevBuf* b : all) s->info.device_bytes += b->bytes;
     }
@@ -776,7 +784,7 @@ yk_status yk_scene_create(yk_context* ctx, const yk_scene_desc* d, yk_scene** ou
 void yk_scene_destroy(yk_scene* s) {
     if (!s) return;
     if (s->device >= 0) (void)hipSetDevice(s->device);
-    DevBuf* all[] = {&s->nodes, &s->nodes4, &s->top_nodes, &s->tris, &s->prim_shade, &s->prim_attr, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
+    DevBuf* all[] = {&s->nodes, &s->nodes4, &s->top_nodes, &s->top_nodes_any, &s->tris, &s->prim_shade, &s->prim_attr, &s->indices, &s->points, &s->normals, &s->uvs, &s->tri_mesh, &s->tri_material, &s->tri_area_light,
                      &s->mesh_flags, &s->materials, &s->lights, &s->spheres, &s->texels, &s->tex_info};
     for (DevBuf* b : all) b->release();
     delete s;

@@ -107,6 +107,8 @@ struct DevScene {
     const DevNode4* nodes4;  // 4-wide collapse of the same tree (null: use `nodes`), root = entry 0
     const DevNode* top_nodes;  // breadth-first copy of the first n_top interior nodes; child refs carry YK_TOP_BIT inside the set
     uint32_t n_top;
+    const DevNode* top_nodes_any;  // the same for the any-hit kernel, which has room for more (4-byte stack entries): its own set, refs consistent within it
+    uint32_t n_top_any;
     const float4* tris;  // 3 per primitive in leaf order: (p0, bits(area_light)) (p1, bits(source shape)) (p2, bits(YK_PRIM_*))
     const uint4* prim_shade;   // per primitive in leaf order: (i0, i1, i2, material << 6 | material kind (MK_*) << 3 | YK_MESH_* flags)
     // per primitive in leaf order, 4 x float4: (n0, uv0.x) (n1, uv0.y) (n2, uv1.x) (uv1.y, uv2.x, uv2.y, 0) — the vertex normals and uvs

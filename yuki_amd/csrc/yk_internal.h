@@ -80,7 +80,7 @@ struct yk_scene {
     bool wide_auto = false;  // both node layouts on the device: the 4-wide one is used for jobs below YK_WIDE_MAX_PATHS
     yk_scene_info info;
     // device
-    DevBuf nodes, nodes4, top_nodes, tris, prim_shade, prim_attr, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights, spheres, texels, tex_info;
+    DevBuf nodes, nodes4, top_nodes, top_nodes_any, tris, prim_shade, prim_attr, indices, points, normals, uvs, tri_mesh, tri_material, tri_area_light, mesh_flags, materials, lights, spheres, texels, tex_info;
     DevScene dev;
     bool on_device = false;
 };

@@ -9,6 +9,7 @@ namespace yk {
 unsigned trace_block_size();
 unsigned trace_spill_depth();
 unsigned trace_top_nodes();
+unsigned trace_top_nodes_any();
 // wave-packet traversal for coherent rays (yk_packet.hip); requires tree depth <= 64
 unsigned packet_blocks_per_cu();
 void launch_trace_closest_packet(hipStream_t s, unsigned grid, const DevScene& sc, const float4* rayO, const float4* rayD, const unsigned* count_ptr,

@@ -53,13 +53,16 @@ Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        // a copy the process already holds first (RTLD_NOLOAD), then the usual names
+        // A copy the process already holds first (RTLD_NOLOAD), then the usual names.  One process, one RCCL: the dynamic
+        // linker matches libraries by soname (librccl.so.1), so whichever copy is loaded first — ours here, or the one a
+        // host such as PyTorch ships and links — serves everybody afterwards.  A host that carries its own RCCL should
+        // load it before the first yk_multi / yk_dist call (the Python tests import torch first for that reason).
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
         for (const char* n : names)
-            if ((r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+            if ((r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) break;
         if (!r.handle)
             for (const char* n : names)
-                if ((r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+                if ((r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
         if (!r.handle) {
             const char* e = dlerror();
             r.error = std::string("RCCL not found (librccl.so.1): ") + (e ? e : "");

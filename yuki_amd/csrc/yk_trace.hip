@@ -26,6 +26,9 @@
 #ifndef TRACE_TOP
 #define TRACE_TOP 95  // interior nodes of the first tree levels kept in LDS (<= YK_TOP_MAX)
 #endif
+#ifndef TRACE_ANY_TOP
+#define TRACE_ANY_TOP 224  // any-hit kernel: its stack entries are 4 bytes (a ref, no entry distance), which leaves LDS for this many top nodes
+#endif
 #ifndef TRACE_MIN_WAVES
 #define TRACE_MIN_WAVES 7  // waves per SIMD the register allocator must leave room for
 #endif
@@ -74,6 +77,24 @@ template <int BLOCK, int LDS_DEPTH> struct TravStack {
     }
 };
 
+// any-hit traversal never re-tests a deferred box, so its stack holds bare refs: half the LDS
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+typedef __attribute__((address_space(1))) unsigned glb_u32;
+template <int BLOCK, int LDS_DEPTH> struct TravStack32 {
+    lds_u32* lds;    // [LDS_DEPTH][BLOCK]
+    glb_u32* spill;  // [YK_STACK_CAP - LDS_DEPTH][spill_stride] (the 8-byte-entry spill buffer, used as words)
+    unsigned spill_stride, gtid;
+    __device__ __forceinline__ void push(int sp, unsigned ref) {
+        if (sp < LDS_DEPTH)
+            lds[sp * BLOCK + threadIdx.x] = ref;
+        else
+            spill[(size_t)(sp - LDS_DEPTH) * spill_stride + gtid] = ref;
+    }
+    __device__ __forceinline__ unsigned at(int sp) const {
+        return sp < LDS_DEPTH ? lds[sp * BLOCK + threadIdx.x] : spill[(size_t)(sp - LDS_DEPTH) * spill_stride + gtid];
+    }
+};
+
 struct NodeBoxes {
     V3 lo0, hi0, lo1, hi1;
     unsigned ref0, ref1, axis;
@@ -109,9 +130,9 @@ __device__ __forceinline__ NodeBoxes load_node_lds(const float4* top, unsigned i
     n.axis = (d.y >> YK_AXIS_SHIFT) & 3u;
     return n;
 }
-template <int BLOCK> __device__ __forceinline__ void fill_top(float4* lds_top, const DevScene& sc) {
-    const float4* src = reinterpret_cast<const float4*>(sc.top_nodes);
-    for (unsigned i = threadIdx.x; i < sc.n_top * 4u; i += BLOCK) lds_top[i] = src[i];
+template <int BLOCK> __device__ __forceinline__ void fill_top(float4* lds_top, const DevNode* top_nodes, unsigned n_top) {
+    const float4* src = reinterpret_cast<const float4*>(top_nodes);
+    for (unsigned i = threadIdx.x; i < n_top * 4u; i += BLOCK) lds_top[i] = src[i];
     __syncthreads();
 }
 
@@ -359,7 +380,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(Dev
                                                             unsigned spill_stride, unsigned* ctrl, unsigned long long* ray_counter) {
     __shared__ unsigned long long lds_stack[LDS_DEPTH * BLOCK];
     __shared__ float4 lds_top[WIDE ? 1 : TRACE_TOP * 4];
-    if (!WIDE) fill_top<BLOCK>(lds_top, sc);
+    if (!WIDE) fill_top<BLOCK>(lds_top, sc.top_nodes, sc.n_top);
     TravStack<BLOCK, LDS_DEPTH> stk;
     stk.lds = (lds_u64*)lds_stack;
     stk.spill = (glb_u64*)spill;
@@ -536,17 +557,17 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScen
                                                         const unsigned* __restrict__ slot_of, const unsigned* count_ptr, unsigned* head,
                                                         unsigned char* __restrict__ vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
                                                         unsigned long long* shadow_counter) {
-    __shared__ unsigned long long lds_stack[LDS_DEPTH * BLOCK];
-    __shared__ float4 lds_top[WIDE ? 1 : TRACE_TOP * 4];
-    if (!WIDE) fill_top<BLOCK>(lds_top, sc);
-    TravStack<BLOCK, LDS_DEPTH> stk;
-    stk.lds = (lds_u64*)lds_stack;
-    stk.spill = (glb_u64*)spill;
+    __shared__ unsigned lds_stack[LDS_DEPTH * BLOCK];
+    __shared__ float4 lds_top[WIDE ? 1 : TRACE_ANY_TOP * 4];
+    if (!WIDE) fill_top<BLOCK>(lds_top, sc.top_nodes_any, sc.n_top_any);
+    TravStack32<BLOCK, LDS_DEPTH> stk;
+    stk.lds = (lds_u32*)lds_stack;
+    stk.spill = (glb_u32*)spill;
     stk.spill_stride = spill_stride;
     stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
     const unsigned n = *count_ptr;
     if (shadow_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(shadow_counter, (unsigned long long)n);
-    const unsigned root = WIDE ? 0u : (sc.n_top ? YK_TOP_BIT : sc.root_ref);
+    const unsigned root = WIDE ? 0u : (sc.n_top_any ? YK_TOP_BIT : sc.root_ref);
     const V3 root_lo = V3{sc.root_bmin[0], sc.root_bmin[1], sc.root_bmin[2]}, root_hi = V3{sc.root_bmax[0], sc.root_bmax[1], sc.root_bmax[2]};
 
     ChunkCursor work;
@@ -612,7 +633,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScen
                                     atomicOr(ctrl + YK_CTRL_ERR, 1u);
                                     sp = 0;
                                 } else {
-                                    stk.push(sp, next, 0.0f);
+                                    stk.push(sp, next);
                                     ++sp;
                                 }
                             }
@@ -623,7 +644,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScen
                         cur = next;
                     } else if (sp > 0) {
                         --sp;
-                        cur = stk.at(sp).x;
+                        cur = stk.at(sp);
                     } else {
                         if (!slot_of) vis[slot] = 0;
                         active = false;  // unoccluded
@@ -643,7 +664,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScen
                             atomicOr(ctrl + YK_CTRL_ERR, 1u);
                             sp = 0;
                         } else {
-                            stk.push(sp, far_ref, 0.0f);
+                            stk.push(sp, far_ref);
                             ++sp;
                         }
                     }
@@ -652,7 +673,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScen
                     cur = far_ref;
                 } else if (sp > 0) {
                     --sp;
-                    cur = stk.at(sp).x;
+                    cur = stk.at(sp);
                 } else {
                     if (!slot_of) vis[slot] = 0;
                     active = false;  // unoccluded
@@ -689,7 +710,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScen
                 active = false;
             } else if (sp > 0) {
                 --sp;
-                cur = stk.at(sp).x;
+                cur = stk.at(sp);
             } else {
                 if (!slot_of) vis[slot] = 0;
                 active = false;
@@ -966,6 +987,8 @@ __global__ __launch_bounds__(BLOCK) void k_whitted(DevScene sc, RenderParams prm
 unsigned trace_block_size() { return TRACE_BLOCK; }
 unsigned trace_spill_depth() { return YK_STACK_CAP - TRACE_LDS; }
 unsigned trace_top_nodes() { return TRACE_TOP; }
+unsigned trace_top_nodes_any() { return TRACE_ANY_TOP; }
+static_assert(TRACE_LDS * TRACE_BLOCK * 4 + TRACE_ANY_TOP * 64 <= TRACE_LDS * TRACE_BLOCK * 8 + TRACE_TOP * 64 + 1024, "the any-hit kernel must fit the block count of the closest-hit kernel");
 unsigned trace_blocks_per_cu() {
     unsigned by_lds = (160u * 1024u) / (TRACE_LDS * TRACE_BLOCK * 8u + TRACE_TOP * 64u);
     unsigned by_waves = (unsigned)TRACE_MIN_WAVES * 256u / TRACE_BLOCK;
