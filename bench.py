@@ -17,9 +17,9 @@ replicated, each rank renders its tiles into HBM and one RCCL gather moves the
 per-tile radiance to rank 0, which scatters it into the film (Film::update_tile).
 Total work is fixed -> "scaling": "strong".  Steps are enqueued without host
 synchronisation, alternately on two contexts (frames in flight = 2), so the latency
-tail of one step overlaps the bulk of the next; N = 1 times synchronous steps (live
-per-kernel HIP-event timings); `--two-in-flight` adds the two-in-flight rate of the same
-steps as `extra.two_in_flight`.
+tail of one step overlaps the bulk of the next — at N = 1 too when the frame is a single
+batch (`--sync-steps` restores one host synchronisation per step).  Per-kernel launch times
+for the roofline come from an untimed probe step in which every launch runs alone.
 
 Metric = the reference's own: closest-hit rays / second (path.rs:87,
 app/window.rs:911-916); shadow rays are traced but not counted.
@@ -156,7 +156,8 @@ def main():
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--async-steps", action="store_true", help="N=1: enqueue the timed steps without host synchronisation, as N>1 always does")
+    ap.add_argument("--async-steps", action="store_true", help="(default since round 2 for frames of one batch) enqueue the timed steps without host synchronisation")
+    ap.add_argument("--sync-steps", action="store_true", help="N=1: one host synchronisation per step inside the timed region (the round-1 mode)")
     ap.add_argument("--cpu-sample-tiles", type=int, default=384)
     ap.add_argument("--rccl-single", action="store_true",
                     help="N=1 through the N>1 code path: a one-rank RCCL process group, asynchronous slots, gather, scatter "
@@ -264,12 +265,17 @@ def main():
     # N > 1 (or --async-steps): every launch of a step — render, RCCL gather, film scatter — is
     # enqueued on one stream and nothing waits on the host inside the timed region;
     # ray counts are taken from one synchronous step beforehand (every step renders the same frame).
-    async_steps = use_dist or args.async_steps
+    # N = 1 runs its timed steps the way N > 1 does — enqueued without host synchronisation, alternating between two contexts —
+    # when the frame is a single batch (the like-for-like base of the scaling figures; the roofline's launch times come from the
+    # solo probe step, not from the timed region).  A frame of several batches already keeps two work sets busy and needs the
+    # HBM for them: it stays on one context with synchronous steps.
+    single_batch = (wl["res"][0] * wl["res"][1] * spp) <= (args.batch_paths or (128 << 20))
+    async_steps = use_dist or args.async_steps or (single_batch and not args.sync_steps)
     # Asynchronous steps alternate between `in_flight` slots — a context (work buffers, HIP
     # streams), a torch stream, a slab and gather buffers each — so that the latency tail of step k
     # (late bounces: few rays, every launch as long as its longest ray) runs beside the bulk of
     # step k+1.  Every slot renders the same scene copy and tile list; steps stay ordered per slot.
-    in_flight = max(1, args.frames_in_flight or (2 if use_dist else 1)) if async_steps else 1
+    in_flight = max(1, args.frames_in_flight or (2 if (use_dist or single_batch) else 1)) if async_steps else 1
     slots = [dict(ctx=ctx, it=it, slab=slab, gathered=gathered, gathered_all=gathered_all, film=film)]
     for _ in range(1, in_flight):
         c2 = yk.Context(local_rank, **opts)
@@ -314,9 +320,11 @@ def main():
         sl["stream"] = torch.cuda.ExternalStream(sl["ctx"].stream_handle, device=dev) if async_steps else None
     step_no = [0]
 
-    def step(want_stats=True):
-        sl = slots[step_no[0] % in_flight]
-        step_no[0] += 1
+    def step(want_stats=True, slot=None):
+        if slot is None:
+            slot = step_no[0] % in_flight
+            step_no[0] += 1
+        sl = slots[slot]
         if sl["stream"] is not None:
             with torch.cuda.stream(sl["stream"]):
                 return step_on(sl, want_stats)
@@ -366,7 +374,7 @@ def main():
     if world == 1 and not use_dist:
         ctx.set_option("overlap_shadow", 0)
         ctx.set_option("streams", 1)  # a frame of several batches: no second work set beside the first either
-        solo = step()
+        solo = step(slot=0)  # `ctx` is slot 0's context
         sync()
         ctx.set_option("overlap_shadow", 1)
         ctx.set_option("streams", 2)
@@ -395,7 +403,7 @@ def main():
     # N = 1, synchronous default: also time the same K steps enqueued asynchronously on two
     # contexts — what N > 1 does by default — so that the scaling figures have a like-for-like base.
     two_in_flight = None
-    if world == 1 and in_flight == 1 and args.two_in_flight:
+    if world == 1 and in_flight == 1 and args.two_in_flight and not async_steps:
         c2 = yk.Context(local_rank, **opts)
         pair = [(ctx, it, slab, film), (c2, yk.IntegratorType.instantiate(c2, integ), torch.zeros_like(slab), torch.zeros_like(film))]
 
