@@ -398,6 +398,7 @@ typedef struct yk_multi_film yk_multi_film;
 /* devices: HIP ordinals, devices[0] assembles the film.  n_devices == 1 is a plain one-GPU
  * render through the same code (no communicator unless "rccl_loopback" is set). */
 yk_status yk_multi_create(const int* devices, uint32_t n_devices, yk_multi** out);
+/* Destroy the films and scenes made from it first or afterwards, in any order; a render must not be in flight. */
 void yk_multi_destroy(yk_multi* m);
 uint32_t yk_multi_device_count(const yk_multi* m);
 /* The context of rank r (options, yk_last_error); owned by the yk_multi. */

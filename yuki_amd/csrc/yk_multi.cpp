@@ -168,6 +168,7 @@ struct yk_multi_scene {
 
 struct yk_multi_film {
     yk_multi* owner = nullptr;
+    std::vector<int> devices;            // copy of the owner's device list: the film frees its buffers without it
     uint16_t res_x = 0, res_y = 0, tile_dim = 0;
     std::vector<yk_tile_list*> lists;    // rank r's tiles, on device r (what it renders)
     std::vector<yk_tile_list*> lists0;   // the same tiles, on device 0 (what it scatters); lists0[0] == lists[0]
@@ -320,16 +321,15 @@ yk_status yk_multi_scene_get_info(const yk_multi_scene* s, yk_scene_info* out) {
 // ------------------------------------------------------------------ film
 void yk_multi_film_destroy(yk_multi_film* f) {
     if (!f) return;
-    yk_multi* m = f->owner;
     for (size_t r = 0; r < f->lists.size(); ++r) {
         if (r < f->lists0.size() && f->lists0[r] && f->lists0[r] != f->lists[r]) yk_tile_list_destroy(f->lists0[r]);
         if (f->lists[r]) yk_tile_list_destroy(f->lists[r]);
     }
-    for (size_t r = 0; r < f->slab.size(); ++r) {
-        (void)hipSetDevice(m->devices[r]);
+    for (size_t r = 0; r < f->slab.size() && r < f->devices.size(); ++r) {
+        (void)hipSetDevice(f->devices[r]);
         f->slab[r].release();
     }
-    (void)hipSetDevice(m->devices[0]);
+    if (!f->devices.empty()) (void)hipSetDevice(f->devices[0]);
     for (DevBuf& b : f->gathered) b.release();
     f->film.release();
     delete f;
@@ -344,6 +344,7 @@ yk_status yk_multi_film_create(yk_multi* m, uint16_t res_x, uint16_t res_y, uint
     if (tiles.size() < G) return mfail(m, YK_ERR_INVALID_ARGUMENT, "fewer tiles than devices");
     std::unique_ptr<yk_multi_film, void (*)(yk_multi_film*)> f(new yk_multi_film(), yk_multi_film_destroy);
     f->owner = m;
+    f->devices = m->devices;
     f->res_x = res_x;
     f->res_y = res_y;
     f->tile_dim = tile_dim;
