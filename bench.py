@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--async-steps", action="store_true", help="(default since round 2 for frames of one batch) enqueue the timed steps without host synchronisation")
+    ap.add_argument("--solo-steps", action="store_true",
+                    help="N=1 diagnostic: every step like the roofline's probe step - side stream off, one work set, one host synchronisation per step - "
+                         "so that a rocprofv3 --kernel-trace --stats summary of this command holds each kernel's own duration (profiles/*_solo_kernel_stats.csv)")
     ap.add_argument("--sync-steps", action="store_true", help="N=1: one host synchronisation per step inside the timed region (the round-1 mode)")
     ap.add_argument("--cpu-sample-tiles", type=int, default=384)
     ap.add_argument("--rccl-single", action="store_true",
@@ -231,6 +234,8 @@ def main():
     opts = {}
     if args.batch_paths:
         opts["batch_paths"] = args.batch_paths
+    if args.solo_steps:
+        opts.update(overlap_shadow=0, streams=1)
     ctx = yk.Context(local_rank, **opts)
     scene = yk.Scene(ctx, sd)  # one device copy, rendered by every context of this rank
     info = scene.info()
@@ -270,6 +275,8 @@ def main():
     # solo probe step, not from the timed region).  A frame of several batches already keeps two work sets busy and needs the
     # HBM for them: it stays on one context with synchronous steps.
     single_batch = (wl["res"][0] * wl["res"][1] * spp) <= (args.batch_paths or (128 << 20))
+    if args.solo_steps:
+        args.sync_steps = True
     async_steps = use_dist or args.async_steps or (single_batch and not args.sync_steps)
     # Asynchronous steps alternate between `in_flight` slots — a context (work buffers, HIP
     # streams), a torch stream, a slab and gather buffers each — so that the latency tail of step k
@@ -376,8 +383,9 @@ def main():
         ctx.set_option("streams", 1)  # a frame of several batches: no second work set beside the first either
         solo = step(slot=0)  # `ctx` is slot 0's context
         sync()
-        ctx.set_option("overlap_shadow", 1)
-        ctx.set_option("streams", 2)
+        if not args.solo_steps:
+            ctx.set_option("overlap_shadow", 1)
+            ctx.set_option("streams", 2)
     t0 = time.perf_counter()
     rays = shadow = 0
     t_trace = t_shadow = t_shade = t_dev = 0.0

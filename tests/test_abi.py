@@ -58,3 +58,20 @@ def test_product_never_references_the_oracle():
                     if re.search(r"(from|import)\s+oracle|#include\s+\"[^\"]*oracle|liboracle|orc_[a-z]", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_multi_gpu_entry_points_fail_loudly_without_a_device():
+    """yk_multi_* / yk_dist_* (include/yuki_hip.h, several GPUs): no device, no fallback."""
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    L = _ffi.lib()
+    devs = (C.c_int * 1)(0)
+    h = C.c_void_p()
+    assert L.yk_multi_create(devs, 1, C.byref(h)) == 2 and not h.value  # YK_ERR_NO_DEVICE
+    assert L.yk_multi_create(devs, 0, C.byref(h)) == 1  # YK_ERR_INVALID_ARGUMENT
+    two = (C.c_int * 2)(0, 0)
+    assert L.yk_multi_create(two, 2, C.byref(h)) == 1  # one rank per GPU
+    assert L.yk_multi_device_count(None) == 0 and not L.yk_multi_film_device_ptr(None)
+    assert L.yk_multi_sync(None) == 1 and L.yk_dist_create(None, None, 0, 1, C.byref(h)) == 1

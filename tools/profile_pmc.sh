@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 pass() {  # name counters...
     local name=$1; shift
     # a counter set the hardware cannot collect makes rocprofv3 abort and then hang: bound every pass
-    timeout -k 5 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline $BENCH_ARGS > /dev/null 2> $OUT/$name.log || echo "pass $name failed (see $name.log)"
+    timeout -k 5 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --solo-steps $BENCH_ARGS > /dev/null 2> $OUT/$name.log || echo "pass $name failed (see $name.log)"
 }
 BENCH_ARGS="$*"
 pass sq SQ_WAVES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES

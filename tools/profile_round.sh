@@ -12,6 +12,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o run -
 f=$(find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1)
 cp $f $O/${TAG}_kernel_stats.csv
 rm -rf $O/${TAG}_stats
+# the same with every launch alone on the GPU (side stream off, one work set): each kernel's own duration, what bench.py's roofline divides by
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_solo_stats -o run -- python3 $R/bench.py --workload $WL --steps 3 --no-cpu-baseline --solo-steps > $O/${TAG}_solo_stats_bench.json 2> $O/${TAG}_solo_stats.log
+f=$(find $O/${TAG}_solo_stats -name "*kernel_stats.csv" | head -1)
+cp $f $O/${TAG}_solo_kernel_stats.csv
+rm -rf $O/${TAG}_solo_stats
 bash $R/tools/profile_pmc.sh $TAG --workload $WL
 cp $O/pmc_$TAG/summary.json $O/${TAG}_pmc_summary.json
-python3 $R/tools/pmc_family.py $O/${TAG}_pmc_summary.json $WL "profiles/${TAG}_pmc_summary.json (tools/profile_round.sh: separate rocprofv3 --pmc passes of bench.py --workload $WL --steps 1 --warmup 0)" > $O/${TAG}_pmc_${WL}.json
+python3 $R/tools/pmc_family.py $O/${TAG}_pmc_summary.json $WL "profiles/${TAG}_pmc_summary.json (tools/profile_round.sh: separate rocprofv3 --pmc passes of bench.py --workload $WL --steps 1 --warmup 0 --no-cpu-baseline --solo-steps)" > $O/${TAG}_pmc_${WL}.json
