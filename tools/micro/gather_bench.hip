@@ -6,6 +6,8 @@
 //           ends up with its own record
 //   modes 3-7 (mode 0 with part of the wave masked off; what does a partially filled gather cost?):
 //     3: lanes 0-31   4: even lanes   5: lanes 0-15   6: one lane per quad (lane % 4 == 0)   7: a random half, new every iteration
+//   modes 8-10 (mode 0 with lanes SHARING records: does the TA merge equal addresses?):
+//     8: the whole wave fetches one record   9: groups of 8 lanes share a record   10: pairs   11: groups of 4   12: groups of 16   13: groups of 32
 // Table size is a parameter (fits L2 / Infinity Cache / HBM).  Prints records/s (records actually fetched).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -25,7 +27,12 @@ template <int MODE> __global__ __launch_bounds__(256, 6) void k(const float4* __
     for (unsigned it = 0; it < iters; ++it) {
         unsigned idx = rng(s) % n_rec;
         float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
-        if (MODE >= 3) {
+        if (MODE >= 8) {
+            const unsigned share = MODE == 8 ? 0u : MODE == 9 ? (lane & ~7u) : MODE == 10 ? (lane & ~1u) : MODE == 11 ? (lane & ~3u) : MODE == 12 ? (lane & ~15u) : (lane & ~31u);
+            idx = __shfl(idx, (int)share);
+            const float4* p = table + (size_t)idx * 4;
+            r0 = p[0]; r1 = p[1]; r2 = p[2]; r3 = p[3];
+        } else if (MODE >= 3) {
             const bool on = MODE == 3 ? lane < 32u : MODE == 4 ? (lane & 1u) == 0u : MODE == 5 ? lane < 16u : MODE == 6 ? (lane & 3u) == 0u : ((idx >> 13) & 1u) != 0u;
             if (on) {
                 const float4* p = table + (size_t)idx * 4;
@@ -66,8 +73,8 @@ int main(int argc, char** argv) {
     hipMemset(table, 0, (size_t)n_rec * 64);
     const int grid = 256 * 6;
     hipMalloc(&out, grid * 256 * 4);
-    const double active[8] = {1.0, 1.0, 1.0, 0.5, 0.5, 0.25, 0.25, 0.5};
-    for (int mode = 0; mode < 8; ++mode) {
+    const double active[14] = {1.0, 1.0, 1.0, 0.5, 0.5, 0.25, 0.25, 0.5, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+    for (int mode = 0; mode < 14; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEvent_t a, b;
             hipEventCreate(&a); hipEventCreate(&b);
@@ -80,6 +87,12 @@ int main(int argc, char** argv) {
             if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
             if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
             if (mode == 7) hipLaunchKernelGGL(k<7>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
+            if (mode == 8) hipLaunchKernelGGL(k<8>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
+            if (mode == 9) hipLaunchKernelGGL(k<9>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
+            if (mode == 10) hipLaunchKernelGGL(k<10>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
+            if (mode == 11) hipLaunchKernelGGL(k<11>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
+            if (mode == 12) hipLaunchKernelGGL(k<12>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
+            if (mode == 13) hipLaunchKernelGGL(k<13>, dim3(grid), dim3(256), 0, 0, table, n_rec, iters, out);
             hipEventRecord(b);
             hipEventSynchronize(b);
             float ms;
