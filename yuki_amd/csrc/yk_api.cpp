@@ -992,7 +992,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         }
         kt.end(e, 1, sb);
         if (n_shadow_launches) ++*n_shadow_launches;
-        launch_accumulate(sb, sg, prm, pc, ws.pend.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ds.n_lights, sample_buf, bc);
+        launch_accumulate(sb, sg, prm, pc, ws.pend.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ds.n_lights, sample_buf, bc, b == 0 ? 1u : 0u);
         if (overlap) (void)hipEventRecord(ws.ev_acc, sb);
         if (kt.on && std::getenv("YK_DEBUG_BOUNCES")) {  // per-bounce breakdown (synchronises; diagnostics only)
             unsigned h[YK_CTRL_STRIDE + 1];

@@ -37,7 +37,7 @@ void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const Render
                   PathBuffers cur, PathBuffers nxt, const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis,
                   unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder, unsigned block_slots);
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
-                       const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* bc);
+                       const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* bc, unsigned first);
 void launch_resolve(hipStream_t s, const float4* sample_buf, uint32_t n_pixels, uint32_t spp, float* out_rgb);
 void launch_resolve_passes(hipStream_t s, const float4* sample_buf, uint32_t n_pixels, uint32_t n_passes, float* out_rgb, size_t pass_stride);
 void launch_film_scatter(hipStream_t s, const uint32_t* pixel_xy, uint32_t n_pixels, const float* tile_rgb, uint32_t res_x, float* film_rgb, int accumulate,

@@ -78,7 +78,9 @@ __global__ void k_raygen(DevCamera cam, RenderParams prm, const uint32_t* pixel_
     out.rayD[i] = make_float4(d.x, d.y, d.z, __uint_as_float((uint32_t)w));
     out.thru[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(st.dimension));
     out.rngs[i] = make_uint4((unsigned)st.rng.state, (unsigned)(st.rng.state >> 32), (unsigned)st.rng.inc, (unsigned)(st.rng.inc >> 32));
-    sample_buf[w] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // The Path integrator's first accumulate pass writes every sample of the batch (every camera ray hits or misses) and
+    // starts from zero itself; only where no such pass follows does the slot have to be cleared here.
+    if (prm.integrator != YK_INTEGRATOR_PATH || prm.max_depth == 0) sample_buf[w] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // Integrator::li entry: caller-supplied rays (yk_li)
@@ -95,7 +97,7 @@ __global__ void k_raygen_user(RenderParams prm, const float* ray_o, const float*
     out.rayD[i] = make_float4(ray_d[3 * i], ray_d[3 * i + 1], ray_d[3 * i + 2], __uint_as_float(i));
     out.thru[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(st.dimension));
     out.rngs[i] = make_uint4((unsigned)st.rng.state, (unsigned)(st.rng.state >> 32), (unsigned)st.rng.inc, (unsigned)(st.rng.inc >> 32));
-    sample_buf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (prm.integrator != YK_INTEGRATOR_PATH || prm.max_depth == 0) sample_buf[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // ------------------------------------------------------------------ shade
@@ -410,8 +412,10 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
 // ------------------------------------------------------------------ accumulate
 // radiance = fold over lights (in light order) of the unoccluded contributions,
 // + beta*Le, clamp, then incoming_radiance += beta * radiance   (path.rs:102-129)
+// `first`: the camera bounce — the sample's radiance so far is zero (raygen does not clear the slot: 0 + x == x bit for bit, a
+// stored +0 included), so the slot is written without being read.
 __global__ void k_accumulate(RenderParams prm, PathBuffers cur, const float4* pend, const float4* shC, const unsigned char* vis, unsigned nl,
-                             float4* sample_buf, const unsigned* bc) {
+                             float4* sample_buf, const unsigned* bc, unsigned first) {
     const unsigned n = bc[0];
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 p = pend[i];
@@ -419,8 +423,11 @@ __global__ void k_accumulate(RenderParams prm, PathBuffers cur, const float4* pe
         unsigned sid = __float_as_uint(cur.rayD[i].w);
         float4 c = cur.thru[i];
         RGB beta = RGB{c.x, c.y, c.z};
-        float4 acc = sample_buf[sid];
-        RGB L = RGB{acc.x, acc.y, acc.z};
+        RGB L = RGB{0.0f, 0.0f, 0.0f};
+        if (!first) {
+            const float4 acc = sample_buf[sid];
+            L = RGB{acc.x, acc.y, acc.z};
+        }
         RGB radiance = RGB{0.0f, 0.0f, 0.0f};
         if (!(kind & YK_PEND_MISS)) {
             for (unsigned l = 0; l < nl; ++l) {
@@ -672,8 +679,8 @@ void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const Render
                        shO2, shD2, shq2, bc, split_delta, reorder, (unsigned)SHADE_WIN, block_slots);
 }
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
-                       const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* bc) {
-    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, prm, cur, pend, shC, vis, nl, sample_buf, bc);
+                       const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* bc, unsigned first) {
+    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, prm, cur, pend, shC, vis, nl, sample_buf, bc, first);
 }
 void launch_resolve(hipStream_t s, const float4* sample_buf, uint32_t n_pixels, uint32_t spp, float* out_rgb) {
     if (!n_pixels) return;
