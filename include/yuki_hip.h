@@ -373,6 +373,13 @@ yk_status yk_bsdf_eval(yk_context* ctx, const yk_material_desc* material, size_t
 yk_status yk_bsdf_sample(yk_context* ctx, const yk_material_desc* material, size_t n, const float* n_geom,
                          const float* n_shading, const float* dpdu, const float* wo, const float* u, float* out8);
 
+/* Light::sample_li (lights/mod.rs:29-32; point_light.rs:27-50, spot_light.rs:32-80, distant_light.rs:24-43,
+ * rectangular_light.rs:46-71) on the device for n surface points against one light, and the ray of the
+ * VisibilityTester it returns (visibility.rs:21-23, interaction.rs:44-59).  out: 18 floats per point —
+ * l[3], li[3], pdf, has_vis (0/1), area_light (light_index or -1), p1[3], shadow-ray origin[3], direction[3]. */
+yk_status yk_light_sample(yk_context* ctx, const yk_light_desc* light, int32_t light_index, size_t n, const float* p,
+                          const float* n_geom, const float* u, float* out18);
+
 size_t yk_sizeof(int what);
 
 /* ---- several GPUs ------------------------------------------------------

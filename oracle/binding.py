@@ -89,6 +89,8 @@ def lib():
     L.orc_bsdf_eval.restype = None
     L.orc_bsdf_sample.argtypes = [C.POINTER(abi.MaterialDesc)] + [vp] * 6
     L.orc_bsdf_sample.restype = None
+    L.orc_light_sample.argtypes = [C.POINTER(abi.LightDesc), C.c_int32, C.c_size_t] + [vp] * 4
+    L.orc_light_sample.restype = None
     L.orc_texture_eval.argtypes = [C.POINTER(abi.TextureDesc), C.c_size_t, vp, vp]
     L.orc_texture_eval.restype = None
     L.orc_sizeof.argtypes = [C.c_int]

@@ -55,6 +55,20 @@ template <class T> static Transform<T> rot_any(int axis, T theta, const T* av) {
 }
 extern "C" {
 
+static Light light_from(const orc_light_desc& l) {
+    Light L;
+    L.kind = (int)l.kind;
+    L.p = Point3f(l.p[0], l.p[1], l.p[2]);
+    L.w = Vec3f(l.p[0], l.p[1], l.p[2]);
+    L.i = sp(l.i);
+    L.cos_total_width = l.cos_total_width;
+    L.cos_falloff_start = l.cos_falloff_start;
+    L.world_to_light = xf_from(l.world_to_light, l.world_to_light);
+    L.sample_to_world = xf_from(l.sample_to_world, l.sample_to_world_inv);
+    L.area = l.area;
+    return L;
+}
+
 int orc_scene_create(const orc_scene_desc* d, orc_scene** out) {
     if (!d || !out) return 1;
     orc_scene* s = new orc_scene();
@@ -94,20 +108,7 @@ int orc_scene_create(const orc_scene_desc* d, orc_scene** out) {
         for (size_t k = 0; k < t.width * t.height; ++k) t.data.push_back(Spectrumf(q[3 * k], q[3 * k + 1], q[3 * k + 2]));
         sc.textures.push_back(t);
     }
-    for (uint32_t i = 0; i < d->n_lights; ++i) {
-        const orc_light_desc& l = d->lights[i];
-        Light L;
-        L.kind = (int)l.kind;
-        L.p = Point3f(l.p[0], l.p[1], l.p[2]);
-        L.w = Vec3f(l.p[0], l.p[1], l.p[2]);
-        L.i = sp(l.i);
-        L.cos_total_width = l.cos_total_width;
-        L.cos_falloff_start = l.cos_falloff_start;
-        L.world_to_light = xf_from(l.world_to_light, l.world_to_light);
-        L.sample_to_world = xf_from(l.sample_to_world, l.sample_to_world_inv);
-        L.area = l.area;
-        sc.lights.push_back(L);
-    }
+    for (uint32_t i = 0; i < d->n_lights; ++i) sc.lights.push_back(light_from(d->lights[i]));
     sc.background = sp(d->background);
     std::vector<Shape>& shapes = s->source_shapes;
     shapes.reserve((size_t)d->n_triangles + d->n_spheres);
@@ -620,6 +621,28 @@ void orc_bsdf_sample(const orc_material_desc* m, const float* n_geom, const floa
     out[3] = s.f.r; out[4] = s.f.g; out[5] = s.f.b;
     out[6] = s.pdf;
     out[7] = (float)s.sample_type;
+}
+
+// Light::sample_li (lights/mod.rs:29-32) and the ray of its VisibilityTester (visibility.rs:21-23) for n surface points
+void orc_light_sample(const orc_light_desc* light, int32_t light_index, size_t n, const float* p, const float* n_geom, const float* u,
+                      float* out18) {
+    const Light L = light_from(*light);
+    for (size_t i = 0; i < n; ++i) {
+        SurfaceInteraction si;
+        si.p = Point3f(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+        si.n = Normalf(n_geom[3 * i], n_geom[3 * i + 1], n_geom[3 * i + 2]);
+        LightSample s = sample_li(L, light_index, si, Point2f(u[2 * i], u[2 * i + 1]));
+        Rayf r = s.vis.ray();
+        float* o = out18 + 18 * i;
+        o[0] = s.l.x; o[1] = s.l.y; o[2] = s.l.z;
+        o[3] = s.li.r; o[4] = s.li.g; o[5] = s.li.b;
+        o[6] = s.pdf;
+        o[7] = s.has_vis ? 1.0f : 0.0f;
+        o[8] = (float)s.vis.area_light;
+        o[9] = s.vis.p1.p.x; o[10] = s.vis.p1.p.y; o[11] = s.vis.p1.p.z;
+        o[12] = r.o.x; o[13] = r.o.y; o[14] = r.o.z;
+        o[15] = r.d.x; o[16] = r.d.y; o[17] = r.d.z;
+    }
 }
 
 void orc_texture_eval(const orc_texture_desc* tex, size_t n, const float* uv, float* out_rgb) {

@@ -212,6 +212,11 @@ void orc_bsdf_eval(const orc_material_desc* m, const float* n_geom, const float*
 void orc_bsdf_sample(const orc_material_desc* m, const float* n_geom, const float* n_shading, const float* dpdu,
                      const float* wo, const float* u, float* out /* wi[3], f[3], pdf, type */);
 
+/* Light::sample_li + VisibilityTester::ray for n surface points against one light; 18 floats per point:
+ * l[3], li[3], pdf, has_vis, area_light, p1[3], shadow-ray origin[3], direction[3] */
+void orc_light_sample(const orc_light_desc* light, int32_t light_index, size_t n, const float* p, const float* n_geom, const float* u,
+                      float* out18);
+
 /* ImageTexture::evaluate at n uv pairs (KAT hook) */
 void orc_texture_eval(const orc_texture_desc* tex, size_t n, const float* uv, float* out_rgb);
 

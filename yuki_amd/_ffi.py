@@ -98,6 +98,7 @@ SYMBOLS = {
     "yk_device_math": (C.c_int, [vp, C.c_int, C.c_size_t, vp, vp, vp]),
     "yk_bsdf_eval": (C.c_int, [vp, C.POINTER(abi.MaterialDesc), C.c_size_t] + [vp] * 6),
     "yk_bsdf_sample": (C.c_int, [vp, C.POINTER(abi.MaterialDesc), C.c_size_t] + [vp] * 6),
+    "yk_light_sample": (C.c_int, [vp, C.POINTER(abi.LightDesc), C.c_int32, C.c_size_t] + [vp] * 4),
     "yk_sizeof": (C.c_size_t, [C.c_int]),
     "yk_load_ply": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
     "yk_load_pbrt": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(vp)]),

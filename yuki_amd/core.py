@@ -589,6 +589,14 @@ def bsdf_eval(ctx, material, n_geom, n_shading, dpdu, wo, wi):
     return out
 
 
+def light_sample(ctx, light, light_index, p, n_geom, u):
+    """Light::sample_li + VisibilityTester::ray on the device: (n, 18) floats, see yk_light_sample"""
+    arrs = [np.ascontiguousarray(x, dtype=np.float32) for x in (p, n_geom, u)]
+    out = np.zeros((arrs[0].shape[0], 18), dtype=np.float32)
+    check(lib().yk_light_sample(ctx.h, C.byref(light), int(light_index), arrs[0].shape[0], *[_p(x) for x in arrs], _p(out)), ctx.h)
+    return out
+
+
 def bsdf_sample(ctx, material, n_geom, n_shading, dpdu, wo, u):
     arrs = [np.ascontiguousarray(x, dtype=np.float32) for x in (n_geom, n_shading, dpdu, wo, u)]
     out = np.zeros((arrs[0].shape[0], 8), dtype=np.float32)

@@ -502,7 +502,6 @@ yk_status yk_build_scene_image(yk_context* ctx, const yk_scene_desc* d, std::sha
                 top.push_back(t);
             }
         };
-        std::vector<DevNode>& top = s->top;
         build_top((size_t)std::min<int64_t>(ctx->top_nodes, trace_top_nodes()), s->top);
         build_top((size_t)std::min<int64_t>(ctx->top_nodes, trace_top_nodes_any()), s->top_any);
         // 4-wide collapse (DevNode4): one node per reference interior node reached at even depth
@@ -1780,6 +1779,29 @@ yk_status yk_bsdf_eval(yk_context* ctx, const yk_material_desc* material, size_t
 yk_status yk_bsdf_sample(yk_context* ctx, const yk_material_desc* material, size_t n, const float* n_geom, const float* n_shading, const float* dpdu,
                          const float* wo, const float* u, float* out8) {
     return bsdf_common(ctx, material, n, n_geom, n_shading, dpdu, wo, u, 1, out8);
+}
+
+yk_status yk_light_sample(yk_context* ctx, const yk_light_desc* light, int32_t light_index, size_t n, const float* p, const float* n_geom,
+                          const float* u, float* out18) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    YK_LOCK(ctx);
+    if (!light || !p || !n_geom || !u || !out18 || n == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null argument");
+    if (light->kind > YK_LIGHT_RECT) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "unknown light kind");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    const float* src[3] = {p, n_geom, u};
+    const size_t each[3] = {3, 3, 2};
+    for (int k = 0; k < 3; ++k) {
+        HIP_TRY(ctx, ctx->scratch[k].ensure(n * each[k] * 4));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[k].p, src[k], n * each[k] * 4, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(ctx, ctx->scratch[5].ensure(n * 18 * 4));
+    launch_light_test(st, make_light(*light), light_index, n, ctx->scratch[0].as<float>(), ctx->scratch[1].as<float>(), ctx->scratch[2].as<float>(),
+                      ctx->scratch[5].as<float>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out18, ctx->scratch[5].p, n * 18 * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return YK_OK;
 }
 
 size_t yk_sizeof(int what) {

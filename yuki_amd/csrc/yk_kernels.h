@@ -47,6 +47,7 @@ void launch_debug_shade(hipStream_t s, const DevScene& sc, uint32_t integrator, 
 void launch_device_math(hipStream_t s, int fn, size_t n, const float* a, const float* b, float* out);
 void launch_sampler_sequence(hipStream_t s, const SamplerCfg& cfg, uint32_t px, uint32_t py, uint32_t sample_index, const uint8_t* dims, size_t n_draws,
                              float* out);
+void launch_light_test(hipStream_t s, const DevLight& L, int index, size_t n, const float* p, const float* ng, const float* u, float* out);
 void launch_bsdf_test(hipStream_t s, const Material& m, size_t n, const float* ng, const float* ns, const float* dpdu, const float* wo,
                       const float* wi_or_u, int sample, float* out);
 void launch_pack_rays(hipStream_t s, size_t n, const float* o, const float* d, float4* rayO, float4* rayD);

@@ -621,6 +621,27 @@ __global__ void k_bsdf_test(Material m, size_t n, const float* ng, const float* 
     }
 }
 
+// Light::sample_li + VisibilityTester::ray for n surface points (stage entry yk_light_sample)
+__global__ void k_light_test(DevLight L, int index, size_t n, const float* p, const float* ng, const float* u, float* out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 sp = ld3(p, (uint32_t)i), nn = ld3(ng, (uint32_t)i);
+    LightSample ls = sample_light(L, index, sp, u[2 * i], u[2 * i + 1]);
+    // p0.spawn_ray_to(p1), interaction.rs:44-59 — as vertex_light does
+    V3 offset = nn * 0.001f;
+    V3 so = dot(ls.p1 - sp, nn) > 0.0f ? sp + offset : sp - offset;
+    V3 sd = ls.p1 - so;
+    float* o = out + 18 * i;
+    o[0] = ls.l.x; o[1] = ls.l.y; o[2] = ls.l.z;
+    o[3] = ls.li.r; o[4] = ls.li.g; o[5] = ls.li.b;
+    o[6] = ls.pdf;
+    o[7] = ls.has_vis ? 1.0f : 0.0f;
+    o[8] = (float)ls.area_light;
+    o[9] = ls.p1.x; o[10] = ls.p1.y; o[11] = ls.p1.z;
+    o[12] = so.x; o[13] = so.y; o[14] = so.z;
+    o[15] = sd.x; o[16] = sd.y; o[17] = sd.z;
+}
+
 __global__ void k_pack_rays(size_t n, const float* o, const float* d, float4* rayO, float4* rayD) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -705,6 +726,9 @@ void launch_device_math(hipStream_t s, int fn, size_t n, const float* a, const f
 void launch_sampler_sequence(hipStream_t s, const SamplerCfg& cfg, uint32_t px, uint32_t py, uint32_t sample_index, const uint8_t* dims, size_t n_draws,
                              float* out) {
     hipLaunchKernelGGL(k_sampler_sequence, dim3(1), dim3(64), 0, s, cfg, px, py, sample_index, dims, n_draws, out);
+}
+void launch_light_test(hipStream_t s, const DevLight& L, int index, size_t n, const float* p, const float* ng, const float* u, float* out) {
+    hipLaunchKernelGGL(k_light_test, dim3(blocks_for(n, 256)), dim3(256), 0, s, L, index, n, p, ng, u, out);
 }
 void launch_bsdf_test(hipStream_t s, const Material& m, size_t n, const float* ng, const float* ns, const float* dpdu, const float* wo,
                       const float* wi_or_u, int sample, float* out) {
