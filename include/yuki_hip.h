@@ -363,9 +363,10 @@ yk_status yk_sampler_sequence(yk_context* ctx, const yk_sampler_desc* sampler, u
 yk_status yk_camera_rays(yk_context* ctx, const yk_camera* camera, const yk_sampler_desc* sampler, const yk_tile* tile,
                          uint32_t sample_index, float* out_o, float* out_d);
 /* device libm used by the kernels: fn 0 sin, 1 cos, 2 tan, 3 log, 4 acos, 5 atan2(x=y_in,y=x_in),
- * 6 sqrt, 7 a/b, 8 f64-sqrt helper, 9 / 10 f32::min / max; 11..21 work on packed triples (n = 3 x count):
+ * 6 sqrt, 7 a/b, 8 f64-sqrt helper, 9 / 10 f32::min / max; 11..27 work on packed triples (n = 3 x count):
  * 11 Vec3::dot, 12 cross, 13 len, 14 normalized, 15 max_dimension, 16 abs, 17 Normal::dot_v, 18 the kx/ky/kz
- * permutation of Triangle::intersect, 19 / 20 Vec3::min / max, 21 Normal::faceforward_v (result in out[3k..3k+2]) */
+ * permutation of Triangle::intersect, 19 / 20 Vec3::min / max, 21 Normal::faceforward_v, 22 a + b, 23 a - b,
+ * 24 a * b.x, 25 a / b.x, 26 -a, 27 len_sqr (result in out[3k..3k+2]) */
 yk_status yk_device_math(yk_context* ctx, int fn, size_t n, const float* a, const float* b, float* out);
 /* Bsdf::f and Bsdf::sample_f on the device for n (wo, wi|u) pairs against one material */
 yk_status yk_bsdf_eval(yk_context* ctx, const yk_material_desc* material, size_t n, const float* n_geom,

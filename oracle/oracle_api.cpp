@@ -569,6 +569,26 @@ void orc_math_kat_f32(int op, const float* a, const float* b, float* out) {
         case 17: out[0] = Point3f(a[0], a[1], a[2]).dist_sqr(Point3f(b[0], b[1], b[2])); break;
         case 18: out[0] = va.len_sqr(); break;
         case 19: put_box(Bounds3f(Point3f(a[0], a[1], a[2]), Point3f(b[0], b[1], b[2]))); break;
+        // operator traits of Vec3 / Point3 / Normal (impl_vec.rs macros: one IEEE operation per component)
+        case 21: { Vec3f r = va + vb; put3(r.x, r.y, r.z); break; }
+        case 22: { Vec3f r = va - vb; put3(r.x, r.y, r.z); break; }
+        case 23: { Vec3f r = va * b[0]; put3(r.x, r.y, r.z); break; }
+        case 24: { Vec3f r = va / b[0]; put3(r.x, r.y, r.z); break; }
+        case 25: out[0] = Normalf(a[0], a[1], a[2]).len(); break;
+        case 26: { Normalf r = Normalf(a[0], a[1], a[2]).normalized(); put3(r.x, r.y, r.z); break; }
+        case 27: {  // Transform::swaps_handedness, transform.rs:85-91 (a: 16 floats, row major)
+            float rows[4][4];
+            for (int i = 0; i < 16; ++i) rows[i / 4][i % 4] = a[i];
+            out[0] = Transformf(Matrix4x4<float>::from_rows(rows), Matrix4x4<float>::from_rows(rows)).swaps_handedness() ? 1.0f : 0.0f;
+            break;
+        }
+        case 28: {  // Matrix4x4::transposed (out: 16 floats)
+            float rows[4][4];
+            for (int i = 0; i < 16; ++i) rows[i / 4][i % 4] = a[i];
+            Matrix4x4<float> t = Matrix4x4<float>::from_rows(rows).transposed();
+            for (int i = 0; i < 16; ++i) out[i] = t.m[i / 4][i % 4];
+            break;
+        }
         default: out[0] = 0.0f;
     }
 }

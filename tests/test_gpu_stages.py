@@ -297,14 +297,16 @@ def test_device_vector_math_replays_the_reference_kats_and_matches_the_oracle(ct
     assert abs(np.linalg.norm(yk.device_math(ctx, 14, f32(v["normalized"]["a"])).astype(np.float64)) - 1.0) < 1e-6
     assert yk.device_math(ctx, 15, f32(v["max_dimension"]["a"]))[0] == v["max_dimension"]["expect"]
     assert yk.device_math(ctx, 17, f32(kats["normal"]["n"]), f32(kats["normal"]["v"]))[0] == kats["normal"]["dot_v"]
-    dev_of = {0: 19, 1: 20, 4: 15, 6: 16}  # orc_math_kat_f32 op -> yk_device_math fn, where the function exists on the device
+    # orc_math_kat_f32 op -> yk_device_math fn, where the function exists on the device
+    dev_of = {0: 19, 1: 20, 4: 15, 6: 16, 7: 26, 18: 27, 21: 22, 22: 23, 23: 24, 24: 25}
     replayed = 0
     for c in kats["more"]["cases"]:
         if c["op"] in dev_of:
-            got = yk.device_math(ctx, dev_of[c["op"]], f32(c["a"]), None if c["b"] is None else f32(c["b"]))
+            b = None if c["b"] is None else f32((list(c["b"]) + [0, 0])[:3])  # a scalar operand travels in b.x
+            got = yk.device_math(ctx, dev_of[c["op"]], f32(c["a"]), b)
             assert np.array_equal(got[: len(c["expect"])], f32(c["expect"])), c["name"]
             replayed += 1
-    assert replayed >= 7
+    assert replayed >= 22
     # tie rules of Vec3::max_dimension (vector.rs:181-195)
     for t, e in (([1, 1, 1], 2), ([2, 1, 2], 2), ([2, 2, 1], 1), ([3, 1, 2], 0)):
         assert yk.device_math(ctx, 15, f32(t))[0] == e

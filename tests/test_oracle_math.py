@@ -6,6 +6,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_math_kats.json")))
 
@@ -203,7 +204,7 @@ def test_coordinate_system_quirk(oracle):
 
 
 def _kat(L, op, a, b):
-    out = np.full(6, np.nan, dtype=np.float32)
+    out = np.full(16, np.nan, dtype=np.float32)
     aa = f32(a)
     bb = None if b is None else f32(b)
     L.orc_math_kat_f32(op, _p(aa), None if bb is None else _p(bb), _p(out))
@@ -215,11 +216,20 @@ def test_remaining_reference_math_tests(oracle):
     exact equality, as the reference's assert_eq! / assert_abs_diff_eq! (default epsilon) on these values demand."""
     L = oracle.lib()
     more = KATS["more"]
-    assert len(more["cases"]) >= 30
+    assert len(more["cases"]) >= 50
     for c in more["cases"]:
         got = _kat(L, c["op"], c["a"], c["b"])
         want = f32(c["expect"])
         assert np.array_equal(got[: len(want)], want), (c["name"], got, want, c["source"])
+    # assert_abs_diff_eq! with the default epsilon (f32::EPSILON)
+    eps = np.finfo(np.float32).eps
+    for c in more["abs_diff_cases"]:
+        got = _kat(L, c["op"], c["a"], c["b"])
+        if "expect_len" in c:
+            n = np.sqrt(got[0] * got[0] + got[1] * got[1] + got[2] * got[2])  # Normal::len: f32 sum left to right, one sqrt
+            assert abs(np.float32(n) - np.float32(c["expect_len"])) <= eps, c["name"]
+        else:
+            assert abs(got[0] - np.float32(c["expect"][0])) <= eps, (c["name"], got[0])
     out = np.zeros(6, dtype=np.float32)
     for c in more["surface_area_more"]:
         box = _kat(L, 19, c["min"], c["max"])  # Bounds3::new sorts the corners first
@@ -238,3 +248,20 @@ def test_remaining_reference_math_tests(oracle):
     assert np.array_equal(centre, f32(bs["center"]))
     r = _kat(L, 16, centre, bs["max"])[0]
     assert r == np.sqrt(np.float32(3 * 1.5 * 1.5))
+
+
+def test_reference_test_map_is_current():
+    """tests/golden/REFERENCE_TESTS.md (which of the reference's 121 unit tests are replayed, by name and line range) is what
+    tools/reference_test_map.py makes of the KAT file's citations today.  Needs the reference's test sources for the names and
+    line ranges, so it runs in the build container only."""
+    import importlib.util, os
+
+    if not os.path.isdir("/root/reference/tests/src"):
+        pytest.skip("reference sources not present on this machine")
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("reference_test_map", os.path.join(here, "tools", "reference_test_map.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text, n_replayed, n_total = mod.render()
+    assert n_total == 121 and n_replayed >= 61
+    assert open(os.path.join(here, "tests", "golden", "REFERENCE_TESTS.md")).read() == text

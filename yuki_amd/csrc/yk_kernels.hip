@@ -556,6 +556,13 @@ __global__ void k_device_math(int fn, size_t n, const float* a, const float* b, 
             case 19: r = V3{rmin(va.x, vb.x), rmin(va.y, vb.y), rmin(va.z, vb.z)}; break;
             case 20: r = V3{rmax(va.x, vb.x), rmax(va.y, vb.y), rmax(va.z, vb.z)}; break;
             case 21: r = faceforward_v(va, vb); break;
+            // the operator traits of Vec3 / Point3 / Normal as the kernels use them (yk_math.h)
+            case 22: r = va + vb; break;
+            case 23: r = va - vb; break;
+            case 24: r = va * vb.x; break;
+            case 25: r = va / vb.x; break;
+            case 26: r = -va; break;
+            case 27: r.x = len_sqr(va); break;
             default: break;
         }
         out[i] = r.x;
