@@ -218,7 +218,7 @@ yk_status yk_last_error(const yk_context* ctx, char* buf, size_t cap);
  * without a second stream: wrap the handle (torch.cuda.ExternalStream, hipStreamWaitEvent ...).
  * Owned by the context; NULL for a NULL context. */
 void* yk_context_stream(const yk_context* ctx);
-/* tuning knobs (none changes any result): "batch_paths" (camera samples per batch),
+/* tuning knobs (none changes any result): "batch_paths" (camera samples per batch, 64 .. 2^29),
  * "streams" (1|2 work sets), "sample_buf_cap" (bytes), "time_kernels" (0 | 1: per-kernel
  * seconds in yk_render_stats for jobs of at least 2^20 samples | 2: always),
  * "packet_bounces" / "packet_shadow_bounces" (leading bounces traced by the wave-packet

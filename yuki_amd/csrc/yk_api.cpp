@@ -129,7 +129,7 @@ yk_status yk_context_set_option(yk_context* ctx, const char* key, int64_t value)
     YK_LOCK(ctx);
     std::string k(key);
     if (k == "batch_paths") {
-        if (value < 64 || value > ((int64_t)1 << 30)) return YK_ERR_INVALID_ARGUMENT;
+        if (value < 64 || value > ((int64_t)1 << 29)) return YK_ERR_INVALID_ARGUMENT;  // 2^29: a path's slot in its batch shares a word with three flag bits
         ctx->batch_paths = value;
     } else if (k == "sample_buf_cap") {
         if (value < (1 << 20)) return YK_ERR_INVALID_ARGUMENT;
@@ -915,7 +915,7 @@ struct KernelTimer {
 // one batch of `n` paths already generated into buffer 0; runs the bounce loop
 static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* scene, const RenderParams& prm, const uint32_t* pixel_xy,
                         const uint32_t* sample_index_tab, float4* sample_buf, KernelTimer& kt, unsigned long long* counters, bool coherent,
-                        uint32_t n_paths, uint32_t* n_shadow_launches = nullptr) {
+                        uint32_t n_paths, uint32_t sid_base, uint32_t* n_shadow_launches = nullptr) {
     unsigned* ctrl = ws.ctrl.as<unsigned>();
     unsigned* errblk = error_block(ctx);  // outlives the batch (ctrl is zeroed per batch)
     // Two node layouts: the binary 64-byte nodes win when the machine is full (one 4-wide node
@@ -970,7 +970,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         e = kt.begin(st);
         launch_shade(st, sg, ds, prm, pixel_xy, sample_index_tab, pc, pn, ws.hit.as<int>(), ws.pend.as<float4>(), ws.shO.as<float4>(),
                      ws.shD.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ws.shq.as<unsigned>(), ws.shO2.as<float4>(),
-                     ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc, split ? 1u : 0u, (b > 0 && ctx->shade_reorder) ? 1u : 0u, 3u * (unsigned)ctx->n_cu);
+                     ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc, split ? 1u : 0u, (b > 0 && ctx->shade_reorder) ? 1u : 0u, 3u * (unsigned)ctx->n_cu, sid_base);
         kt.end(e, 2, st);
         if (overlap) {
             (void)hipEventRecord(ws.ev_shade, st);
@@ -991,7 +991,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         }
         kt.end(e, 1, sb);
         if (n_shadow_launches) ++*n_shadow_launches;
-        launch_accumulate(sb, sg, prm, pc, ws.pend.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ds.n_lights, sample_buf, bc, b == 0 ? 1u : 0u);
+        launch_accumulate(sb, sg, prm, pc, ws.pend.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ds.n_lights, sample_buf, bc, b == 0 ? 1u : 0u, sid_base);
         if (overlap) (void)hipEventRecord(ws.ev_acc, sb);
         if (kt.on && std::getenv("YK_DEBUG_BOUNCES")) {  // per-bounce breakdown (synchronises; diagnostics only)
             unsigned h[YK_CTRL_STRIDE + 1];
@@ -1191,7 +1191,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
             launch_raygen(bs, cam, prm, pixel_xy, pixel_sample, w0, n, path_buffers(ws, 0), sample_buf, ctrl + YK_CTRL_BOUNCE(0));
             ++n_batches;
             if (is_path) {
-                run_bounces(ctx, ws, bs, scene, prm, pixel_xy, pixel_sample, sample_buf, kt, counters, true, n, &n_shadow);
+                run_bounces(ctx, ws, bs, scene, prm, pixel_xy, pixel_sample, sample_buf, kt, counters, true, n, (uint32_t)w0, &n_shadow);
                 n_trace += prm.max_depth;
             } else if (prm.integrator == YK_INTEGRATOR_WHITTED) {
                 // one lane per camera sample runs the whole recursion (whitted.rs:74-181)
@@ -1545,7 +1545,7 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
         launch_whitted(st, trace_grid(ctx), scene->dev, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), path_buffers(ctx->ws[0], 0), (uint32_t)n,
                        ctx->sample_buf.as<float4>(), ctx->ws[0].spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), error_block(ctx), counters);
     else
-        run_bounces(ctx, ctx->ws[0], st, scene, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), ctx->sample_buf.as<float4>(), kt, counters, false, (uint32_t)n);
+        run_bounces(ctx, ctx->ws[0], st, scene, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), ctx->sample_buf.as<float4>(), kt, counters, false, (uint32_t)n, 0u);
     HIP_TRY(ctx, hipGetLastError());
     std::vector<float> tmp(n * 4);
     unsigned host_err[4];

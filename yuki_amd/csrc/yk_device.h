@@ -10,7 +10,7 @@
 //     rngs[i] = (state.lo, state.hi, inc.lo, inc.hi)          PCG32 stream of the pixel
 //   per bounce, not carried:
 //     hit[i]                       source triangle or -1             (trace -> shade)
-//     pend[i] = (rgb, bits(kind))  emission / background term        (shade -> accumulate)
+//     pend[i] = (rgb, kind << 29 | sample slot in the batch)  emission / background term   (shade -> accumulate)
 //     shO/shD/shC[i*n_lights+l]    NEE shadow ray + its contribution (shade -> shadow -> accumulate)
 //     vis[i*n_lights+l]            0 none, 1 pending/visible, 2 occluded
 //     shq[k]                       compacted list of pending shadow slots

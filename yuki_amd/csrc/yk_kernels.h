@@ -35,9 +35,9 @@ void launch_trace_any(hipStream_t s, unsigned grid, const DevScene& sc, const fl
                       unsigned long long* shadow_counter);
 void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                   PathBuffers cur, PathBuffers nxt, const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis,
-                  unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder, unsigned block_slots);
+                  unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder, unsigned block_slots, unsigned sid_base);
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
-                       const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* bc, unsigned first);
+                       const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* bc, unsigned first, unsigned sid_base);
 void launch_resolve(hipStream_t s, const float4* sample_buf, uint32_t n_pixels, uint32_t spp, float* out_rgb);
 void launch_resolve_passes(hipStream_t s, const float4* sample_buf, uint32_t n_pixels, uint32_t n_passes, float* out_rgb, size_t pass_stride);
 void launch_film_scatter(hipStream_t s, const uint32_t* pixel_xy, uint32_t n_pixels, const float* tile_rgb, uint32_t res_x, float* film_rgb, int accumulate,

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
                                                  PathBuffers cur, PathBuffers nxt,
                                                  const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis,
                                                  unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder,
-                                                 unsigned win_max, unsigned block_slots) {
+                                                 unsigned win_max, unsigned block_slots, unsigned sid_base) {
     // `bc`: this bounce's words of the control block (yk_device.h); the next bounce's follow it
     // iterations per window: a full queue sorts win_max (<= SHADE_WIN) x 256 paths together; a queue too short to give every
     // resident block (`block_slots` of them on the device) a full window takes shorter ones, down to one iteration
@@ -379,7 +379,8 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
                     nR = make_uint4((unsigned)st.rng.state, (unsigned)(st.rng.state >> 32), (unsigned)st.rng.inc, (unsigned)(st.rng.inc >> 32));
                 }
             }
-            pend[i] = make_float4(term.r, term.g, term.b, __uint_as_float(kind));
+            // the sample's slot travels with the term (as its offset in the batch, < 2^29): k_accumulate reads no path state for it
+            pend[i] = make_float4(term.r, term.g, term.b, __uint_as_float((kind << YK_PEND_KIND_SHIFT) | (sid - sid_base)));
         }
         YK_PROF_STAMP(4)
         // ---- stream compaction of the survivors into the other buffer
@@ -415,14 +416,17 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
 // `first`: the camera bounce — the sample's radiance so far is zero (raygen does not clear the slot: 0 + x == x bit for bit, a
 // stored +0 included), so the slot is written without being read.
 __global__ void k_accumulate(RenderParams prm, PathBuffers cur, const float4* pend, const float4* shC, const unsigned char* vis, unsigned nl,
-                             float4* sample_buf, const unsigned* bc, unsigned first) {
+                             float4* sample_buf, const unsigned* bc, unsigned first, unsigned sid_base) {
     const unsigned n = bc[0];
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 p = pend[i];
-        unsigned kind = __float_as_uint(p.w);
-        unsigned sid = __float_as_uint(cur.rayD[i].w);
-        float4 c = cur.thru[i];
-        RGB beta = RGB{c.x, c.y, c.z};
+        const unsigned kind = __float_as_uint(p.w) >> YK_PEND_KIND_SHIFT;
+        const unsigned sid = sid_base + (__float_as_uint(p.w) & YK_PEND_SID_MASK);
+        RGB beta = RGB{0.0f, 0.0f, 0.0f};  // the throughput the vertex was entered with; a miss adds its term as it is
+        if (!(kind & YK_PEND_MISS)) {
+            const float4 c = cur.thru[i];
+            beta = RGB{c.x, c.y, c.z};
+        }
         RGB L = RGB{0.0f, 0.0f, 0.0f};
         if (!first) {
             const float4 acc = sample_buf[sid];
@@ -702,13 +706,13 @@ void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, 
 void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                   PathBuffers cur, PathBuffers nxt,
                   const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis, unsigned* shq, float4* shO2,
-                  float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder, unsigned block_slots) {
+                  float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder, unsigned block_slots, unsigned sid_base) {
     hipLaunchKernelGGL((k_shade<256, SHADE_CAP, SHADE_CAPQ>), dim3(grid), dim3(256), 0, s, sc, prm, pixel_xy, sample_index_tab, cur, nxt, hit_tri, pend, shO, shD, shC, vis, shq,
-                       shO2, shD2, shq2, bc, split_delta, reorder, (unsigned)SHADE_WIN, block_slots);
+                       shO2, shD2, shq2, bc, split_delta, reorder, (unsigned)SHADE_WIN, block_slots, sid_base);
 }
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
-                       const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* bc, unsigned first) {
-    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, prm, cur, pend, shC, vis, nl, sample_buf, bc, first);
+                       const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* bc, unsigned first, unsigned sid_base) {
+    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, prm, cur, pend, shC, vis, nl, sample_buf, bc, first, sid_base);
 }
 void launch_resolve(hipStream_t s, const float4* sample_buf, uint32_t n_pixels, uint32_t spp, float* out_rgb) {
     if (!n_pixels) return;

@@ -72,6 +72,9 @@ __device__ __forceinline__ NeeSample vertex_light(const DevScene& sc, const Rend
 #define YK_PEND_MISS 1u
 #define YK_PEND_EMISSION 2u
 #define YK_PEND_CLAMP 4u
+// pend[i].w = kind << 29 | (sample slot - first slot of the batch); batches hold at most 2^29 paths (yk_context_set_option)
+#define YK_PEND_KIND_SHIFT 29
+#define YK_PEND_SID_MASK 0x1fffffffu
 
 // path.rs:155-160: incoming_radiance += beta * scene.background; break
 __device__ __forceinline__ RGB vertex_miss_term(const DevScene& sc, RGB beta) { return beta * RGB{sc.background[0], sc.background[1], sc.background[2]}; }
