@@ -79,6 +79,60 @@ def test_png_large_random_exercises_dynamic_huffman(tmp_path, oi):
     assert got.tobytes() == (src.astype(np.float32) / np.float32(255)).tobytes()
 
 
+REFERENCE_PNGS = [
+    "/root/reference/res/tiling_58-1K/tiling_58_normal-1K.png",  # 1024 x 1024, 16-bit RGBA
+    "/root/reference/res/tiling_58-1K/tiling_58_roughness-1K.png",  # 1024 x 1024, 16-bit grey
+    "/root/reference/screenshot.png",  # 1922 x 1119, 8-bit RGBA
+]
+
+
+@pytest.mark.parametrize("path", REFERENCE_PNGS)
+def test_png_files_the_reference_ships(oi, path):
+    """The PNG files in the reference's own tree (its texture assets and its screenshot: files written by other encoders, 1.7 MB
+    of dynamic-Huffman deflate in the largest) through the product decoder and through the independent zlib / numpy one: same
+    texels, bit for bit, the first row also against a by-hand unfiltering of zlib's output; the 16-bit grey map is refused by both
+    with the reference's own message (a Spectrum texture has no Luma arm).  Read where they lie (build container only)."""
+    import os
+    import struct
+    import zlib
+
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present on this machine")
+    raw = open(path, "rb").read()
+    w, h, depth, ctype = struct.unpack(">IIBB", raw[16:26])
+    if ctype in (0, 4):  # Luma / LumaA: `load_image_spectrum_f32` has no arm for them (image_texture.rs:114-141)
+        with pytest.raises(YukiError, match="Unsupported image format"):
+            loaders.load_image_texture(path)
+        with pytest.raises(Exception, match="Unsupported image format"):
+            oi.load_png(path)
+        return
+    got = loaders.load_image_texture(path)
+    want = oi.load_png(path)
+    assert got.shape == (h, w, 3) and got.tobytes() == want.tobytes()
+    # a third reading of the first row: inflate with zlib, undo the row filter by hand (colour types 0 and 6)
+    pos, idat = 8, b""
+    while pos < len(raw):
+        n, tag = struct.unpack(">I4s", raw[pos : pos + 8])
+        if tag == b"IDAT":
+            idat += raw[pos + 8 : pos + 8 + n]
+        pos += 12 + n
+    chans = {0: 1, 6: 4}[ctype]
+    bpp = chans * depth // 8
+    stride = w * bpp
+    data = zlib.decompress(idat)
+    assert len(data) == h * (stride + 1)
+    f, row = data[0], bytearray(data[1 : 1 + stride])
+    assert f in (0, 1, 2, 3, 4)
+    if f in (1, 3, 4):  # Sub / Average / Paeth with no row above: left neighbour, half of it, left neighbour
+        for i in range(bpp, stride):
+            left = row[i - bpp]
+            row[i] = (row[i] + (left if f != 3 else left // 2)) & 255
+    px = np.frombuffer(bytes(row), dtype=">u2" if depth == 16 else np.uint8).reshape(w, chans).astype(np.float32)
+    px = px / np.float32((1 << depth) - 1)
+    first = np.repeat(px, 3, axis=1) if chans == 1 else px[:, :3]
+    assert got[0].tobytes() == first.tobytes()
+
+
 def test_png_errors(tmp_path, oi):
     src = sf.test_pattern(9, 6)
     p = str(tmp_path / "g.png")
