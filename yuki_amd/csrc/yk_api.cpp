@@ -831,7 +831,7 @@ static yk_status ensure_work_buffers(yk_context* ctx, WorkSet& ws, size_t paths,
     HIP_TRY(ctx, ws.shO2.ensure(paths * nd * 16));
     HIP_TRY(ctx, ws.shD2.ensure(paths * nd * 16));
     HIP_TRY(ctx, ws.shq2.ensure(paths * nd * 4));
-    HIP_TRY(ctx, ws.ctrl.ensure(YK_CTRL_WORDS * 4));
+    HIP_TRY(ctx, ws.ctrl.ensure(YK_CTRL_ALLOC_WORDS * 4));
     ws.cap_paths = paths;
     ws.cap_lights = nl;
     ws.cap_area = na;
@@ -912,10 +912,15 @@ struct KernelTimer {
     }
 };
 
+// camera rays (and the leading bounces the "packet_bounces" option names) go to the wave-packet kernel
+static bool packet_kernel_traces_bounce(const yk_context* ctx, const yk_scene* scene, unsigned b) {
+    return b < (unsigned)ctx->packet_bounces && scene->bvh->depth <= 64;
+}
+
 // one batch of `n` paths already generated into buffer 0; runs the bounce loop
 static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* scene, const RenderParams& prm, const uint32_t* pixel_xy,
                         const uint32_t* sample_index_tab, float4* sample_buf, KernelTimer& kt, unsigned long long* counters, bool coherent,
-                        uint32_t n_paths, uint32_t sid_base, uint32_t* n_shadow_launches = nullptr) {
+                        uint32_t n_paths, uint32_t sid_base, bool lean_camera_bounce, uint32_t* n_shadow_launches = nullptr) {
     unsigned* ctrl = ws.ctrl.as<unsigned>();
     unsigned* errblk = error_block(ctx);  // outlives the batch (ctrl is zeroed per batch)
     // Two node layouts: the binary 64-byte nodes win when the machine is full (one 4-wide node
@@ -952,7 +957,9 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         PathBuffers pc = path_buffers(ws, (int)cur), pn = path_buffers(ws, (int)(cur ^ 1u));
         // camera rays (consecutive samples of a pixel) and the shadow rays they spawn are coherent:
         // the wave walks the tree once for all 64 of them (yk_packet.hip)
-        const bool packet = coherent && b < (unsigned)ctx->packet_bounces && scene->bvh->depth <= 64;
+        const bool packet = coherent && packet_kernel_traces_bounce(ctx, scene, b);
+        // lean camera bounce (yk_device.h, YK_CTRL_CAM_O): raygen stored neither origins nor throughputs
+        const float4* lean_origin = (b == 0 && lean_camera_bounce) ? reinterpret_cast<const float4*>(ctrl + YK_CTRL_CAM_O) : nullptr;
         const bool packet_shadow = coherent && b < (unsigned)ctx->packet_shadow_bounces && scene->bvh->depth <= 64 && scene->n_delta_lights > 0;
         // shadow rays are split into two queues only when the second one gets the packet kernel;
         // otherwise everything goes to the first queue and one launch traces it
@@ -961,7 +968,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         unsigned* bc = ctrl + YK_CTRL_BOUNCE(b);  // this bounce's counters and queue heads, zeroed with the batch
         int e = kt.begin(st);
         if (packet)
-            launch_trace_closest_packet(st, pg, ds, pc.rayO, pc.rayD, bc, bc + YK_CTRL_HEAD, ws.hit.as<int>(), counters);
+            launch_trace_closest_packet(st, pg, ds, lean_origin ? nullptr : pc.rayO, pc.rayD, bc, bc + YK_CTRL_HEAD, ws.hit.as<int>(), counters, lean_origin);
         else
             launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, bc, bc + YK_CTRL_HEAD, ws.hit.as<int>(), nullptr, nullptr,
                                  ws.spill.as<uint2>(), spill_stride, errblk, counters);
@@ -970,7 +977,7 @@ static void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_s
         e = kt.begin(st);
         launch_shade(st, sg, ds, prm, pixel_xy, sample_index_tab, pc, pn, ws.hit.as<int>(), ws.pend.as<float4>(), ws.shO.as<float4>(),
                      ws.shD.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ws.shq.as<unsigned>(), ws.shO2.as<float4>(),
-                     ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc, split ? 1u : 0u, (b > 0 && ctx->shade_reorder) ? 1u : 0u, 3u * (unsigned)ctx->n_cu, sid_base);
+                     ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc, split ? 1u : 0u, (b > 0 && ctx->shade_reorder) ? 1u : 0u, 3u * (unsigned)ctx->n_cu, sid_base, lean_origin);
         kt.end(e, 2, st);
         if (overlap) {
             (void)hipEventRecord(ws.ev_shade, st);
@@ -1188,10 +1195,13 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
             unsigned* ctrl = ws.ctrl.as<unsigned>();
             const uint32_t n = (uint32_t)std::min<uint64_t>(batch, work - w0);
             HIP_TRY(ctx, hipMemsetAsync(ctrl, 0, YK_CTRL_WORDS * 4, bs));
-            launch_raygen(bs, cam, prm, pixel_xy, pixel_sample, w0, n, path_buffers(ws, 0), sample_buf, ctrl + YK_CTRL_BOUNCE(0));
+            // Path, camera rays traced by the packet kernel: the lean camera bounce (yk_device.h, YK_CTRL_CAM_O)
+            const bool lean = is_path && prm.max_depth > 0 && packet_kernel_traces_bounce(ctx, scene, 0);
+            launch_raygen(bs, cam, prm, pixel_xy, pixel_sample, w0, n, path_buffers(ws, 0), sample_buf, ctrl + YK_CTRL_BOUNCE(0),
+                          lean ? reinterpret_cast<float4*>(ctrl + YK_CTRL_CAM_O) : nullptr);
             ++n_batches;
             if (is_path) {
-                run_bounces(ctx, ws, bs, scene, prm, pixel_xy, pixel_sample, sample_buf, kt, counters, true, n, (uint32_t)w0, &n_shadow);
+                run_bounces(ctx, ws, bs, scene, prm, pixel_xy, pixel_sample, sample_buf, kt, counters, true, n, (uint32_t)w0, lean, &n_shadow);
                 n_trace += prm.max_depth;
             } else if (prm.integrator == YK_INTEGRATOR_WHITTED) {
                 // one lane per camera sample runs the whole recursion (whitted.rs:74-181)
@@ -1545,7 +1555,7 @@ yk_status yk_li(yk_context* ctx, const yk_scene* scene, const yk_sampler_desc* s
         launch_whitted(st, trace_grid(ctx), scene->dev, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), path_buffers(ctx->ws[0], 0), (uint32_t)n,
                        ctx->sample_buf.as<float4>(), ctx->ws[0].spill.as<uint2>(), trace_grid(ctx) * trace_block_size(), error_block(ctx), counters);
     else
-        run_bounces(ctx, ctx->ws[0], st, scene, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), ctx->sample_buf.as<float4>(), kt, counters, false, (uint32_t)n, 0u);
+        run_bounces(ctx, ctx->ws[0], st, scene, prm, ctx->pixel_xy.as<uint32_t>(), ctx->scratch[7].as<uint32_t>(), ctx->sample_buf.as<float4>(), kt, counters, false, (uint32_t)n, 0u, false);
     HIP_TRY(ctx, hipGetLastError());
     std::vector<float> tmp(n * 4);
     unsigned host_err[4];

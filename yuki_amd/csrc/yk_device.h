@@ -155,6 +155,12 @@ struct PathBuffers {
 // points (yk_trace_closest / yk_trace_any) use word 0 as the ray count and YK_CTRL_HEADS as head.
 #define YK_CTRL_WORDS 1024
 #define YK_CTRL_ERR 3
+// A float4 BEHIND the zeroed words (its own cache line: the words above are hammered by queue atomics): the camera's ray
+// origin, written by raygen.  The camera bounce of a Path render whose rays go to the wave-packet kernel is "lean": every
+// ray starts there with throughput one, so raygen stores neither rayO nor thru and the packet kernel, k_shade and
+// k_accumulate of that bounce take the constants instead of reading 48 bytes per path.
+#define YK_CTRL_CAM_O (YK_CTRL_WORDS + 32)
+#define YK_CTRL_ALLOC_WORDS (YK_CTRL_WORDS + 64)
 #define YK_CTRL_HEADS 8
 #define YK_CTRL_STRIDE 8
 #define YK_CTRL_BOUNCE(b) (8 + YK_CTRL_STRIDE * (b))

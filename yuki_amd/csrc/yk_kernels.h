@@ -12,8 +12,9 @@ unsigned trace_top_nodes();
 unsigned trace_top_nodes_any();
 // wave-packet traversal for coherent rays (yk_packet.hip); requires tree depth <= 64
 unsigned packet_blocks_per_cu();
+// rayO == nullptr: every ray starts at *lean_origin (the lean camera bounce, yk_device.h)
 void launch_trace_closest_packet(hipStream_t s, unsigned grid, const DevScene& sc, const float4* rayO, const float4* rayD, const unsigned* count_ptr,
-                                 unsigned* head, int* hit_tri, unsigned long long* ray_counter);
+                                 unsigned* head, int* hit_tri, unsigned long long* ray_counter, const float4* lean_origin = nullptr);
 void launch_trace_any_packet(hipStream_t s, unsigned grid, const DevScene& sc, const float4* shO, const float4* shD, const unsigned* slot_of,
                              const unsigned* count_ptr, unsigned* head, unsigned char* vis, unsigned long long* shadow_counter);
 unsigned trace_blocks_per_cu();
@@ -21,7 +22,7 @@ unsigned trace_blocks_per_cu();
 void launch_pixel_table(hipStream_t s, const yk_tile* tiles, const uint32_t* tile_offset, uint32_t n_tiles, uint32_t n_pixels, uint32_t* pixel_xy,
                         const uint16_t* tile_sample = nullptr, uint32_t* pixel_sample = nullptr);
 void launch_raygen(hipStream_t s, const DevCamera& cam, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* pixel_sample, uint64_t work0,
-                   uint32_t n, PathBuffers out, float4* sample_buf, unsigned* ctrl);
+                   uint32_t n, PathBuffers out, float4* sample_buf, unsigned* count, float4* lean_origin = nullptr);
 void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, const float* d, const uint16_t* pixel, const uint32_t* sample_index,
                         uint32_t dimension, uint32_t n, PathBuffers out, float4* sample_buf, uint32_t* pixel_xy, unsigned* ctrl);
 void launch_trace_closest(hipStream_t s, unsigned grid, const DevScene& sc, const float4* rayO, const float4* rayD, const float* t_max_opt,
@@ -35,7 +36,7 @@ void launch_trace_any(hipStream_t s, unsigned grid, const DevScene& sc, const fl
                       unsigned long long* shadow_counter);
 void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                   PathBuffers cur, PathBuffers nxt, const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis,
-                  unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder, unsigned block_slots, unsigned sid_base);
+                  unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder, unsigned block_slots, unsigned sid_base, const float4* lean_origin);
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
                        const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* bc, unsigned first, unsigned sid_base);
 void launch_resolve(hipStream_t s, const float4* sample_buf, uint32_t n_pixels, uint32_t spp, float* out_rgb);

@@ -60,7 +60,7 @@ __device__ __forceinline__ void camera_ray(const DevCamera& cam, float fx, float
 // `pixel_sample` != null: the accumulating film (integrators/mod.rs:146-161) — prm.spe passes of ONE sample per
 // pixel whose global index is the tile's FilmTile.sample; otherwise all spp samples.
 __global__ void k_raygen(DevCamera cam, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* pixel_sample, uint64_t work0, uint32_t n,
-                         PathBuffers out, float4* sample_buf, unsigned* count) {
+                         PathBuffers out, float4* sample_buf, unsigned* count, float4* lean_origin) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *count = n;
     if (i >= n) return;
@@ -74,9 +74,13 @@ __global__ void k_raygen(DevCamera cam, RenderParams prm, const uint32_t* pixel_
     sampler_get_2d(prm.sampler, st, ux, uy);
     V3 o, d;
     camera_ray(cam, (float)px + ux, (float)py + uy, o, d);
-    out.rayO[i] = make_float4(o.x, o.y, o.z, __uint_as_float(0u));
+    if (lean_origin) {  // yk_device.h, YK_CTRL_CAM_O: one origin for all, throughput one, two sampler dimensions drawn
+        if (i == 0) *lean_origin = make_float4(o.x, o.y, o.z, __uint_as_float(0u));
+    } else {
+        out.rayO[i] = make_float4(o.x, o.y, o.z, __uint_as_float(0u));
+        out.thru[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(st.dimension));
+    }
     out.rayD[i] = make_float4(d.x, d.y, d.z, __uint_as_float((uint32_t)w));
-    out.thru[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(st.dimension));
     out.rngs[i] = make_uint4((unsigned)st.rng.state, (unsigned)(st.rng.state >> 32), (unsigned)st.rng.inc, (unsigned)(st.rng.inc >> 32));
     // The Path integrator's first accumulate pass writes every sample of the batch (every camera ray hits or misses) and
     // starts from zero itself; only where no such pass follows does the slot have to be cleared here.
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
                                                  PathBuffers cur, PathBuffers nxt,
                                                  const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis,
                                                  unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder,
-                                                 unsigned win_max, unsigned block_slots, unsigned sid_base) {
+                                                 unsigned win_max, unsigned block_slots, unsigned sid_base, const float4* __restrict__ lean_origin) {
     // `bc`: this bounce's words of the control block (yk_device.h); the next bounce's follow it
     // iterations per window: a full queue sorts win_max (<= SHADE_WIN) x 256 paths together; a queue too short to give every
     // resident block (`block_slots` of them on the device) a full window takes shorter ones, down to one iteration
@@ -306,7 +310,16 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
         v.fr.s = v.fr.t = v.fr.n = v.fr.ng = V3{0, 0, 1};
         v.wo = V3{0, 0, 1};
         if (valid) {
-            float4 a = cur.rayO[i], b = cur.rayD[i], c = cur.thru[i];
+            // lean camera bounce (yk_device.h, YK_CTRL_CAM_O): the shared origin, throughput one, the camera sample's two dimensions
+            float4 a, c;
+            const float4 b = cur.rayD[i];
+            if (lean_origin) {  // kernel argument: a wave-uniform branch
+                a = *lean_origin;
+                c = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(2u));
+            } else {
+                a = cur.rayO[i];
+                c = cur.thru[i];
+            }
             uint4 r = cur.rngs[i];
             o = f4_xyz(a);
             d = f4_xyz(b);
@@ -422,8 +435,8 @@ __global__ void k_accumulate(RenderParams prm, PathBuffers cur, const float4* pe
         float4 p = pend[i];
         const unsigned kind = __float_as_uint(p.w) >> YK_PEND_KIND_SHIFT;
         const unsigned sid = sid_base + (__float_as_uint(p.w) & YK_PEND_SID_MASK);
-        RGB beta = RGB{0.0f, 0.0f, 0.0f};  // the throughput the vertex was entered with; a miss adds its term as it is
-        if (!(kind & YK_PEND_MISS)) {
+        RGB beta = RGB{1.0f, 1.0f, 1.0f};  // the throughput the vertex was entered with (one at the camera's); a miss adds its term as it is
+        if (!first && !(kind & YK_PEND_MISS)) {
             const float4 c = cur.thru[i];
             beta = RGB{c.x, c.y, c.z};
         }
@@ -695,8 +708,8 @@ void launch_pixel_table(hipStream_t s, const yk_tile* tiles, const uint32_t* til
                        pixel_sample);
 }
 void launch_raygen(hipStream_t s, const DevCamera& cam, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* pixel_sample, uint64_t work0,
-                   uint32_t n, PathBuffers out, float4* sample_buf, unsigned* ctrl) {
-    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 256)), dim3(256), 0, s, cam, prm, pixel_xy, pixel_sample, work0, n, out, sample_buf, ctrl);
+                   uint32_t n, PathBuffers out, float4* sample_buf, unsigned* count, float4* lean_origin) {
+    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 256)), dim3(256), 0, s, cam, prm, pixel_xy, pixel_sample, work0, n, out, sample_buf, count, lean_origin);
 }
 void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, const float* d, const uint16_t* pixel, const uint32_t* sample_index,
                         uint32_t dimension, uint32_t n, PathBuffers out, float4* sample_buf, uint32_t* pixel_xy, unsigned* ctrl) {
@@ -706,9 +719,9 @@ void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, 
 void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                   PathBuffers cur, PathBuffers nxt,
                   const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis, unsigned* shq, float4* shO2,
-                  float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder, unsigned block_slots, unsigned sid_base) {
+                  float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder, unsigned block_slots, unsigned sid_base, const float4* lean_origin) {
     hipLaunchKernelGGL((k_shade<256, SHADE_CAP, SHADE_CAPQ>), dim3(grid), dim3(256), 0, s, sc, prm, pixel_xy, sample_index_tab, cur, nxt, hit_tri, pend, shO, shD, shC, vis, shq,
-                       shO2, shD2, shq2, bc, split_delta, reorder, (unsigned)SHADE_WIN, block_slots, sid_base);
+                       shO2, shD2, shq2, bc, split_delta, reorder, (unsigned)SHADE_WIN, block_slots, sid_base, lean_origin);
 }
 void launch_accumulate(hipStream_t s, unsigned grid, const RenderParams& prm, PathBuffers cur, const float4* pend, const float4* shC,
                        const unsigned char* vis, unsigned nl, float4* sample_buf, const unsigned* bc, unsigned first, unsigned sid_base) {

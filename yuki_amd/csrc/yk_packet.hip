@@ -191,7 +191,7 @@ __device__ __forceinline__ void pkt_closest_group(const DevScene& sc, PktStack& 
 template <bool SPHERES>
 __global__ __launch_bounds__(YK_PKT_BLOCK, 8) void k_trace_closest_packet(DevScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
                                                                           const unsigned* count_ptr, unsigned* head, int* __restrict__ hit_tri,
-                                                                          unsigned long long* ray_counter) {
+                                                                          unsigned long long* ray_counter, const float4* __restrict__ lean_origin) {
     __shared__ uint4 lds_stack[(YK_PKT_BLOCK / YK_WAVE) * YK_PKT_STACK];
     PktStack stk;
     stk.base = lds_stack + (threadIdx.x / YK_WAVE) * YK_PKT_STACK;
@@ -215,7 +215,8 @@ __global__ __launch_bounds__(YK_PKT_BLOCK, 8) void k_trace_closest_packet(DevSce
         bool alive = false;
         int best = -1;
         {
-            const float4 ro = valid ? rayO[idx] : make_float4(0, 0, 0, 0), rd = valid ? rayD[idx] : make_float4(0, 0, 1, 0);
+            // rayO == null: the lean camera bounce, all rays start at the camera's origin (yk_device.h, YK_CTRL_CAM_O)
+            const float4 ro = !valid ? make_float4(0, 0, 0, 0) : (rayO ? rayO[idx] : *lean_origin), rd = valid ? rayD[idx] : make_float4(0, 0, 1, 0);
             r.o = f4_xyz(ro);
             r.d = f4_xyz(rd);
             r.inv = V3{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
@@ -369,11 +370,11 @@ __global__ __launch_bounds__(YK_PKT_BLOCK, 8) void k_trace_any_packet(DevScene s
 unsigned packet_blocks_per_cu() { return 8u; }
 
 void launch_trace_closest_packet(hipStream_t s, unsigned grid, const DevScene& sc, const float4* rayO, const float4* rayD, const unsigned* count_ptr,
-                                 unsigned* head, int* hit_tri, unsigned long long* ray_counter) {
+                                 unsigned* head, int* hit_tri, unsigned long long* ray_counter, const float4* lean_origin) {
     if (sc.spheres)
-        hipLaunchKernelGGL((k_trace_closest_packet<true>), dim3(grid), dim3(YK_PKT_BLOCK), 0, s, sc, rayO, rayD, count_ptr, head, hit_tri, ray_counter);
+        hipLaunchKernelGGL((k_trace_closest_packet<true>), dim3(grid), dim3(YK_PKT_BLOCK), 0, s, sc, rayO, rayD, count_ptr, head, hit_tri, ray_counter, lean_origin);
     else
-        hipLaunchKernelGGL((k_trace_closest_packet<false>), dim3(grid), dim3(YK_PKT_BLOCK), 0, s, sc, rayO, rayD, count_ptr, head, hit_tri, ray_counter);
+        hipLaunchKernelGGL((k_trace_closest_packet<false>), dim3(grid), dim3(YK_PKT_BLOCK), 0, s, sc, rayO, rayD, count_ptr, head, hit_tri, ray_counter, lean_origin);
 }
 void launch_trace_any_packet(hipStream_t s, unsigned grid, const DevScene& sc, const float4* shO, const float4* shD, const unsigned* slot_of,
                              const unsigned* count_ptr, unsigned* head, unsigned char* vis, unsigned long long* shadow_counter) {

@@ -29,6 +29,9 @@
 #ifndef TRACE_ANY_TOP
 #define TRACE_ANY_TOP 224  // any-hit kernel: its stack entries are 4 bytes (a ref, no entry distance), which leaves LDS for this many top nodes
 #endif
+#ifndef TRACE_ANY_LDS
+#define TRACE_ANY_LDS TRACE_LDS  // any-hit kernel: stack entries per lane kept in LDS (>= TRACE_LDS: both kernels share the spill buffer's depth)
+#endif
 #ifndef TRACE_MIN_WAVES
 #define TRACE_MIN_WAVES 7  // waves per SIMD the register allocator must leave room for
 #endif
@@ -988,7 +991,8 @@ unsigned trace_block_size() { return TRACE_BLOCK; }
 unsigned trace_spill_depth() { return YK_STACK_CAP - TRACE_LDS; }
 unsigned trace_top_nodes() { return TRACE_TOP; }
 unsigned trace_top_nodes_any() { return TRACE_ANY_TOP; }
-static_assert(TRACE_LDS * TRACE_BLOCK * 4 + TRACE_ANY_TOP * 64 <= TRACE_LDS * TRACE_BLOCK * 8 + TRACE_TOP * 64 + 1024, "the any-hit kernel must fit the block count of the closest-hit kernel");
+static_assert(TRACE_ANY_LDS * TRACE_BLOCK * 4 + TRACE_ANY_TOP * 64 <= TRACE_LDS * TRACE_BLOCK * 8 + TRACE_TOP * 64 + 1024, "the any-hit kernel must fit the block count of the closest-hit kernel");
+static_assert(TRACE_ANY_LDS >= TRACE_LDS, "the spill buffer is sized for TRACE_LDS entries in LDS");
 unsigned trace_blocks_per_cu() {
     unsigned by_lds = (160u * 1024u) / (TRACE_LDS * TRACE_BLOCK * 8u + TRACE_TOP * 64u);
     unsigned by_waves = (unsigned)TRACE_MIN_WAVES * 256u / TRACE_BLOCK;
@@ -1027,7 +1031,7 @@ void launch_trace_any(hipStream_t s, unsigned grid, const DevScene& sc, const fl
                       const unsigned* count_ptr, unsigned* head, unsigned char* vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
                       unsigned long long* shadow_counter) {
 #define YK_LAUNCH_ANY(SPH, WIDE)                                                                                                                       \
-    hipLaunchKernelGGL((k_trace_any_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, SPH, WIDE>), dim3(grid),     \
+    hipLaunchKernelGGL((k_trace_any_pt<TRACE_BLOCK, TRACE_ANY_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, SPH, WIDE>), dim3(grid),     \
                        dim3(TRACE_BLOCK), 0, s, sc, shO, shD, slot_of, count_ptr, head, vis, spill, spill_stride, ctrl, shadow_counter)
     if (sc.spheres) {
         if (sc.nodes4) YK_LAUNCH_ANY(true, true); else YK_LAUNCH_ANY(true, false);
