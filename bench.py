@@ -459,6 +459,9 @@ def main():
             # test, 36 B per triangle test (oracle counters) — are mostly L1 / LDS / L2 hits, not HBM bytes: they are
             # reported as `algorithmic`, never as an HBM fraction.
             pmc_d, pmc_src = pmc_traffic(args.workload)
+            if args.batch_paths:  # the tracked per-launch counters were collected with the default batch size: another one has other launches
+                log("[bench] --batch-paths given: the PMC-based roofline entries (traffic, TA busy, L1 / L2 rates) are left out")
+                pmc_d, pmc_src = {}, None
             table_bytes = int(info.n_interior) * 64 + int(info.n_shapes) * 48  # what the lanes gather from: 64-B nodes, 48-B triangles
             ceil_l1 = gather_ceiling(0)
             ceil_tab = gather_ceiling(table_bytes)
