@@ -1159,6 +1159,14 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         if (prepared) {  // the pixel table of the whole list is already on the device
             pixel_xy = prepared->pixel_xy.as<uint32_t>() + px0;
             if (accumulating) pixel_sample = prepared->pixel_sample.as<uint32_t>() + px0;
+        } else if (t_end - t_begin == 1) {  // one tile (the reference's per-tile call): it travels as a kernel argument
+            HIP_TRY(ctx, ctx->pixel_xy.ensure((size_t)npx * 4));
+            pixel_xy = ctx->pixel_xy.as<uint32_t>();
+            if (accumulating) {
+                HIP_TRY(ctx, ctx->scratch[5].ensure((size_t)npx * 4));
+                pixel_sample = ctx->scratch[5].as<uint32_t>();
+            }
+            launch_pixel_table_one(st, tiles[t_begin], npx, pixel_xy, accumulating ? tile_samples[t_begin] : 0u, pixel_sample);
         } else {
         std::vector<uint32_t> loc(t_end - t_begin + 1);
         for (size_t t = t_begin; t <= t_end; ++t) loc[t - t_begin] = off[t] - px0;

@@ -21,6 +21,7 @@ unsigned trace_blocks_per_cu();
 
 void launch_pixel_table(hipStream_t s, const yk_tile* tiles, const uint32_t* tile_offset, uint32_t n_tiles, uint32_t n_pixels, uint32_t* pixel_xy,
                         const uint16_t* tile_sample = nullptr, uint32_t* pixel_sample = nullptr);
+void launch_pixel_table_one(hipStream_t s, const yk_tile& tile, uint32_t n_pixels, uint32_t* pixel_xy, uint32_t tile_sample, uint32_t* pixel_sample);
 void launch_raygen(hipStream_t s, const DevCamera& cam, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* pixel_sample, uint64_t work0,
                    uint32_t n, PathBuffers out, float4* sample_buf, unsigned* count, float4* lean_origin = nullptr);
 void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, const float* d, const uint16_t* pixel, const uint32_t* sample_index,

@@ -47,6 +47,16 @@ __global__ void k_pixel_table(const yk_tile* tiles, const uint32_t* tile_offset,
     if (tile_sample) pixel_sample[i] = tile_sample[lo];  // FilmTile.sample of the pixel's tile (accumulating film)
 }
 
+// the same for a chunk of ONE tile — the reference's per-tile Integrator::render call: the tile travels as a kernel argument
+// (no upload, no host synchronisation for the staging buffer)
+__global__ void k_pixel_table_one(yk_tile t, uint32_t n_pixels, uint32_t* pixel_xy, uint32_t tile_sample, uint32_t* pixel_sample) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    uint32_t w = (uint32_t)t.x1 - t.x0;
+    pixel_xy[i] = (t.x0 + i % w) | ((t.y0 + i / w) << 16);
+    if (pixel_sample) pixel_sample[i] = tile_sample;
+}
+
 // ------------------------------------------------------------------ raygen
 // sampler.start_pixel_sample(p, sample_index, 0); p_film = p + get_2d();
 // ray = camera.ray(p_film)     integrators/mod.rs:163-169, camera.rs:105-114
@@ -706,6 +716,10 @@ void launch_pixel_table(hipStream_t s, const yk_tile* tiles, const uint32_t* til
     if (!n_pixels) return;
     hipLaunchKernelGGL(k_pixel_table, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, tiles, tile_offset, n_tiles, n_pixels, pixel_xy, tile_sample,
                        pixel_sample);
+}
+void launch_pixel_table_one(hipStream_t s, const yk_tile& tile, uint32_t n_pixels, uint32_t* pixel_xy, uint32_t tile_sample, uint32_t* pixel_sample) {
+    if (!n_pixels) return;
+    hipLaunchKernelGGL(k_pixel_table_one, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, tile, n_pixels, pixel_xy, tile_sample, pixel_sample);
 }
 void launch_raygen(hipStream_t s, const DevCamera& cam, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* pixel_sample, uint64_t work0,
                    uint32_t n, PathBuffers out, float4* sample_buf, unsigned* count, float4* lean_origin) {
