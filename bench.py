@@ -309,8 +309,16 @@ def main():
                 for k, sl in enumerate(slots):
                     key = f"yk_dist_id_{k}"
                     if rank == 0:
-                        store.set(key, yk.Dist.unique_id())
-                    sl["dist"] = yk.Dist(sl["ctx"], bytes(store.get(key)), rank, world)
+                        try:
+                            uid = yk.Dist.unique_id()
+                        except Exception as e:  # noqa: BLE001 - publish the failure: the other ranks must not wait for an id
+                            log(f"[bench] rank 0: no RCCL id ({e})")
+                            uid = b""
+                        store.set(key, uid)
+                    uid = bytes(store.get(key))
+                    if len(uid) != yk.Dist.ID_BYTES:
+                        raise RuntimeError("rank 0 could not create an RCCL unique id")
+                    sl["dist"] = yk.Dist(sl["ctx"], uid, rank, world)
             except Exception as e:  # noqa: BLE001 - any failure means: use the other carrier, on every rank
                 log(f"[bench] rank {rank}: yk_dist unavailable ({e}); falling back to torch.distributed.gather")
                 ok = 0.0

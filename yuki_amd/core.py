@@ -413,6 +413,8 @@ class Dist:
     """One process per GPU (yk_dist): join an RCCL communicator with this rank's context; gather()
     moves every rank's slab into rank 0's buffer on the context's stream."""
 
+    ID_BYTES = 128  # YK_DIST_ID_BYTES
+
     @staticmethod
     def unique_id():
         buf = (C.c_uint8 * 128)()
