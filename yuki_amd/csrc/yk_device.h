@@ -8,6 +8,8 @@
 //     rayD[i] = (d.x, d.y, d.z, bits(sample_id))    sample_id = index into sample_buf
 //     thru[i] = (beta.r, beta.g, beta.b, bits(sampler dimension))
 //     rngs[i] = (state.lo, state.hi, inc.lo, inc.hi)          PCG32 stream of the pixel
+//     (camera bounce of a Path render traced by the packet kernel: rayO and thru are NOT stored — one origin for all,
+//      throughput one; see YK_CTRL_CAM_O)
 //   per bounce, not carried:
 //     hit[i]                       source triangle or -1             (trace -> shade)
 //     pend[i] = (rgb, kind << 29 | sample slot in the batch)  emission / background term   (shade -> accumulate)
@@ -15,7 +17,7 @@
 //     vis[i*n_lights+l]            0 none, 1 pending/visible, 2 occluded
 //     shq[k]                       compacted list of pending shadow slots
 //   per chunk:
-//     sample_buf[sample_id] = (L.r, L.g, L.b, -)    radiance of one camera sample
+//     sample_buf[sample_id] = (L.r, L.g, L.b, -)    radiance of one camera sample (Path: first written by k_accumulate of the camera bounce)
 //     pixel_xy[pixel]       = x | y<<16             pixel of each chunk-local pixel index
 #pragma once
 #include <hip/hip_runtime.h>
