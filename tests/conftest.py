@@ -3,6 +3,15 @@ import sys
 
 import pytest
 
+# PyTorch ships its own HIP runtime and RCCL (torch/lib); libyuki_hip.so links the system ones under the same sonames.  One
+# process holds one copy of each — whichever is loaded first — and PyTorch does not initialise on the system runtime
+# ("No HIP GPUs are available"), so the tests that use torch for device buffers need it loaded BEFORE the library, whatever
+# subset or order of tests runs.  (A host that brings its own HIP stack does the same: load it first.)
+try:
+    import torch  # noqa: F401
+except ImportError:  # CPU-only checkouts without torch still run the oracle / host tests
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

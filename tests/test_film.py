@@ -106,6 +106,36 @@ def test_film_accumulate_host(yk, oracle):
 
 
 @pytest.mark.gpu
+def test_one_tile_per_call_like_the_reference(ctx, yk, oracle):
+    """Integrator::render as the reference's workers call it — ONE tile per call (render_worker.rs:230-250), plain and
+    accumulating (FilmTile.sample = 0 .. spp - 1): a one-tile chunk passes its tile as a kernel argument (k_pixel_table_one);
+    pixels and ray counts equal the oracle's for ragged edge tiles too, and the samples fold into the plain result."""
+    sd = scenes.by_name("city-tiny")
+    fs = yk.FilmSettings(res=(70, 41), tile_dim=16)  # 6-wide and 9-high tiles at the right / bottom edge
+    cam = yk.Camera(sd.camera, fs)
+    tiles = yk.film_tiles(fs)
+    sampler = yk.SamplerType.Stratified((2, 2), True, 0x51C0FFEE)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=6))
+    it = yk.IntegratorType.instantiate(ctx, integ)
+    sc = yk.Scene(ctx, sd)
+    osc = oracle.OracleScene(sd)
+    picked = [tiles[0], tiles[len(tiles) // 2], tiles[-1], max(tiles, key=lambda t: int(t["x0"])), max(tiles, key=lambda t: int(t["y0"]))]
+    for t in picked:
+        one = np.array([tuple(int(v) for v in t)], dtype=abi.TILE_DTYPE)
+        got, rays = it.render(sc, cam, sampler, yk.FilmTile(tuple(int(v) for v in t)))
+        want, orays = osc.render_tiles(cam.matrices, sampler, integ, one, n_threads=0)
+        assert rays == orays and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        acc = np.zeros_like(got)
+        for k in range(4):
+            px, r = it.render(sc, cam, sampler, yk.FilmTile(tuple(int(v) for v in t), sample=k), accumulating=True)
+            owant, _ = osc.render_tiles_accumulating(cam.matrices, sampler, integ, one, np.array([k], dtype=np.uint16), n_threads=0)
+            assert np.array_equal(px.view(np.uint32), owant.view(np.uint32))
+            acc = acc + px  # Film::update_tile's `+=` in sample order (film.rs:260-272)
+        assert np.array_equal((acc / np.float32(4)).view(np.uint32), got.view(np.uint32))
+    sc.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("skind", ["uniform", "stratified"])
 def test_accumulating_render_matches_oracle(ctx, yk, oracle, skind):
     sd = scenes.by_name("city-tiny")
