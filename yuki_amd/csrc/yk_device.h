@@ -183,4 +183,16 @@ struct RenderParams {
     uint32_t spe;
 };
 
+// sample id -> (entry of the pixel table, sample within the entry): id = entry * spe + k.  `spe` is uniform and nearly always a
+// power of two (8x8, 16x16 strata; 1 for yk_li): a shift and a mask then, the division otherwise.
+__device__ __forceinline__ void split_sample_id(uint32_t sid, uint32_t spe, uint32_t& entry, uint32_t& k) {
+    if ((spe & (spe - 1u)) == 0u) {
+        entry = sid >> (31u - (uint32_t)__clz((int)spe));
+        k = sid & (spe - 1u);
+    } else {
+        entry = sid / spe;
+        k = sid % spe;
+    }
+}
+
 }  // namespace yk

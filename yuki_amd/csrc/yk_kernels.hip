@@ -74,9 +74,10 @@ __global__ void k_raygen(DevCamera cam, RenderParams prm, const uint32_t* pixel_
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *count = n;
     if (i >= n) return;
-    uint64_t w = work0 + i;
-    const uint32_t pix = (uint32_t)(w / prm.spe);
-    const uint32_t s = (pixel_sample ? pixel_sample[pix] : 0u) + (uint32_t)(w % prm.spe);
+    const uint32_t w = (uint32_t)(work0 + i);  // a chunk holds fewer than 2^32 samples (it indexes sample_buf)
+    uint32_t pix, ks;
+    split_sample_id(w, prm.spe, pix, ks);
+    const uint32_t s = (pixel_sample ? pixel_sample[pix] : 0u) + ks;
     uint32_t xy = pixel_xy[pix];
     uint32_t px = xy & 0xffffu, py = xy >> 16;
     SamplerState st = sampler_start(prm.sampler, px, py, s, 0);
@@ -342,11 +343,12 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
             st.rng.inc = (u64)r.z | ((u64)r.w << 32);
             st.dimension = __float_as_uint(c.w);
             // film renders: sample_id = pixel*spp + sample ; yk_li: one table entry per ray
-            const uint32_t pix = sid / prm.spe;  // entry of the pixel table (yk_device.h: RenderParams::spe)
+            uint32_t pix, ks;  // entry of the pixel table and sample within it (yk_device.h: RenderParams::spe)
+            split_sample_id(sid, prm.spe, pix, ks);
             uint32_t xy = pixel_xy[pix];
             st.px = xy & 0xffffu;
             st.py = xy >> 16;
-            st.sample_index = (sample_index_tab ? sample_index_tab[pix] : 0u) + sid % prm.spe;
+            st.sample_index = (sample_index_tab ? sample_index_tab[pix] : 0u) + ks;
             int tri = hit_tri[i];
             hit = tri >= 0;
             if (hit) vertex_setup(sc, (uint32_t)tri & YK_HIT_PRIM_MASK, o, d, v);  // the leaf-order slot reported by the render-loop trace kernels

@@ -861,11 +861,12 @@ __global__ __launch_bounds__(BLOCK) void k_whitted(DevScene sc, RenderParams prm
         st.rng.state = (u64)r.x | ((u64)r.y << 32);
         st.rng.inc = (u64)r.z | ((u64)r.w << 32);
         st.dimension = __float_as_uint(c.w);
-        const uint32_t pix = sid / prm.spe;
+        uint32_t pix, ks;
+        split_sample_id(sid, prm.spe, pix, ks);
         const uint32_t xy = pixel_xy[pix];
         st.px = xy & 0xffffu;
         st.py = xy >> 16;
-        st.sample_index = (sample_index_tab ? sample_index_tab[pix] : 0u) + sid % prm.spe;
+        st.sample_index = (sample_index_tab ? sample_index_tab[pix] : 0u) + ks;
         WhittedFrame frames[YK_WHITTED_MAX_DEPTH];
         int sp = 0;  // frames on the stack = depth of the call being evaluated
         bool is_specular = false;
