@@ -108,7 +108,7 @@ void yk_context_destroy(yk_context* ctx) {
     if (ctx->ws[1].stream) (void)hipStreamDestroy(ctx->ws[1].stream);
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
     if (ctx->ev_out) (void)hipEventDestroy(ctx->ev_out);
-    DevBuf* all[] = {&ctx->sample_buf, &ctx->pixel_xy, &ctx->tiles, &ctx->tile_off, &ctx->counters, &ctx->stats4, &ctx->hit4};
+    DevBuf* all[] = {&ctx->sample_buf, &ctx->pixel_xy, &ctx->pixel_aux, &ctx->tiles, &ctx->tile_off, &ctx->counters, &ctx->stats4, &ctx->hit4};
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : ctx->scratch) b.release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -1184,6 +1184,9 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         }
         launch_pixel_table(st, ctx->tiles.as<yk_tile>(), ctx->tile_off.as<uint32_t>(), (uint32_t)(t_end - t_begin), npx, pixel_xy, d_tile_sample, pixel_sample);
         }
+        // the pixel's share of every camera sample's sampler start, once per pixel (yk_rng.h, PixelSampler)
+        HIP_TRY(ctx, ctx->pixel_aux.ensure((size_t)npx * 16));
+        launch_pixel_sampler(st, prm.sampler, pixel_xy, npx, ctx->pixel_aux.as<uint4>());
         // the second stream starts after the pixel table exists
         if (n_ws == 2) {
             HIP_TRY(ctx, hipEventRecord(ctx->ws[0].done, st));
@@ -1206,7 +1209,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
             // Path, camera rays traced by the packet kernel: the lean camera bounce (yk_device.h, YK_CTRL_CAM_O)
             const bool lean = is_path && prm.max_depth > 0 && packet_kernel_traces_bounce(ctx, scene, 0);
             launch_raygen(bs, cam, prm, pixel_xy, pixel_sample, w0, n, path_buffers(ws, 0), sample_buf, ctrl + YK_CTRL_BOUNCE(0),
-                          lean ? reinterpret_cast<float4*>(ctrl + YK_CTRL_CAM_O) : nullptr);
+                          lean ? reinterpret_cast<float4*>(ctrl + YK_CTRL_CAM_O) : nullptr, ctx->pixel_aux.as<uint4>());
             ++n_batches;
             if (is_path) {
                 run_bounces(ctx, ws, bs, scene, prm, pixel_xy, pixel_sample, sample_buf, kt, counters, true, n, (uint32_t)w0, lean, &n_shadow);

@@ -62,7 +62,7 @@ struct yk_context {
         hipStream_t side = nullptr;  // shadow rays + accumulate of bounce b run here beside trace of bounce b+1
         hipEvent_t done = nullptr, ev_shade = nullptr, ev_acc = nullptr;
     } ws[2];
-    DevBuf sample_buf, pixel_xy, tiles, tile_off, counters, stats4, hit4, scratch[8];
+    DevBuf sample_buf, pixel_xy, pixel_aux, tiles, tile_off, counters, stats4, hit4, scratch[8];
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;  // hand-over between a caller's stream and the context's own
     // every entry point that touches the context's buffers or streams holds this: calls on one

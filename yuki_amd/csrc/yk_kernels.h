@@ -23,7 +23,8 @@ void launch_pixel_table(hipStream_t s, const yk_tile* tiles, const uint32_t* til
                         const uint16_t* tile_sample = nullptr, uint32_t* pixel_sample = nullptr);
 void launch_pixel_table_one(hipStream_t s, const yk_tile& tile, uint32_t n_pixels, uint32_t* pixel_xy, uint32_t tile_sample, uint32_t* pixel_sample);
 void launch_raygen(hipStream_t s, const DevCamera& cam, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* pixel_sample, uint64_t work0,
-                   uint32_t n, PathBuffers out, float4* sample_buf, unsigned* count, float4* lean_origin = nullptr);
+                   uint32_t n, PathBuffers out, float4* sample_buf, unsigned* count, float4* lean_origin = nullptr, const uint4* pixel_aux = nullptr);
+void launch_pixel_sampler(hipStream_t s, const SamplerCfg& cfg, const uint32_t* pixel_xy, uint32_t n_pixels, uint4* pixel_aux);
 void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, const float* d, const uint16_t* pixel, const uint32_t* sample_index,
                         uint32_t dimension, uint32_t n, PathBuffers out, float4* sample_buf, uint32_t* pixel_xy, unsigned* ctrl);
 void launch_trace_closest(hipStream_t s, unsigned grid, const DevScene& sc, const float4* rayO, const float4* rayD, const float* t_max_opt,

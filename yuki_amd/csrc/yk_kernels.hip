@@ -57,6 +57,15 @@ __global__ void k_pixel_table_one(yk_tile t, uint32_t n_pixels, uint32_t* pixel_
     if (pixel_sample) pixel_sample[i] = tile_sample;
 }
 
+// per-pixel part of the camera samples' sampler start (yk_rng.h, PixelSampler): (stream.lo, stream.hi, hash0, -)
+__global__ void k_pixel_sampler(SamplerCfg cfg, const uint32_t* pixel_xy, uint32_t n_pixels, uint4* pixel_aux) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const uint32_t xy = pixel_xy[i];
+    const PixelSampler ps = pixel_sampler(cfg, xy & 0xffffu, xy >> 16);
+    pixel_aux[i] = make_uint4((unsigned)ps.stream, (unsigned)(ps.stream >> 32), ps.hash0, 0u);
+}
+
 // ------------------------------------------------------------------ raygen
 // sampler.start_pixel_sample(p, sample_index, 0); p_film = p + get_2d();
 // ray = camera.ray(p_film)     integrators/mod.rs:163-169, camera.rs:105-114
@@ -70,7 +79,7 @@ __device__ __forceinline__ void camera_ray(const DevCamera& cam, float fx, float
 // `pixel_sample` != null: the accumulating film (integrators/mod.rs:146-161) — prm.spe passes of ONE sample per
 // pixel whose global index is the tile's FilmTile.sample; otherwise all spp samples.
 __global__ void k_raygen(DevCamera cam, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* pixel_sample, uint64_t work0, uint32_t n,
-                         PathBuffers out, float4* sample_buf, unsigned* count, float4* lean_origin) {
+                         PathBuffers out, float4* sample_buf, unsigned* count, float4* lean_origin, const uint4* pixel_aux) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *count = n;
     if (i >= n) return;
@@ -80,9 +89,18 @@ __global__ void k_raygen(DevCamera cam, RenderParams prm, const uint32_t* pixel_
     const uint32_t s = (pixel_sample ? pixel_sample[pix] : 0u) + ks;
     uint32_t xy = pixel_xy[pix];
     uint32_t px = xy & 0xffffu, py = xy >> 16;
-    SamplerState st = sampler_start(prm.sampler, px, py, s, 0);
+    SamplerState st;
     float ux, uy;
-    sampler_get_2d(prm.sampler, st, ux, uy);
+    if (pixel_aux) {  // the pixel's share of the work was done once per pixel (k_pixel_sampler)
+        const uint4 a = pixel_aux[pix];
+        PixelSampler ps;
+        ps.stream = (u64)a.x | ((u64)a.y << 32);
+        ps.hash0 = a.z;
+        st = sampler_start_camera(prm.sampler, ps, px, py, s, ux, uy);
+    } else {
+        st = sampler_start(prm.sampler, px, py, s, 0);
+        sampler_get_2d(prm.sampler, st, ux, uy);
+    }
     V3 o, d;
     camera_ray(cam, (float)px + ux, (float)py + uy, o, d);
     if (lean_origin) {  // yk_device.h, YK_CTRL_CAM_O: one origin for all, throughput one, two sampler dimensions drawn
@@ -723,9 +741,13 @@ void launch_pixel_table_one(hipStream_t s, const yk_tile& tile, uint32_t n_pixel
     if (!n_pixels) return;
     hipLaunchKernelGGL(k_pixel_table_one, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, tile, n_pixels, pixel_xy, tile_sample, pixel_sample);
 }
+void launch_pixel_sampler(hipStream_t s, const SamplerCfg& cfg, const uint32_t* pixel_xy, uint32_t n_pixels, uint4* pixel_aux) {
+    if (!n_pixels) return;
+    hipLaunchKernelGGL(k_pixel_sampler, dim3(blocks_for(n_pixels, 256)), dim3(256), 0, s, cfg, pixel_xy, n_pixels, pixel_aux);
+}
 void launch_raygen(hipStream_t s, const DevCamera& cam, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* pixel_sample, uint64_t work0,
-                   uint32_t n, PathBuffers out, float4* sample_buf, unsigned* count, float4* lean_origin) {
-    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 256)), dim3(256), 0, s, cam, prm, pixel_xy, pixel_sample, work0, n, out, sample_buf, count, lean_origin);
+                   uint32_t n, PathBuffers out, float4* sample_buf, unsigned* count, float4* lean_origin, const uint4* pixel_aux) {
+    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 256)), dim3(256), 0, s, cam, prm, pixel_xy, pixel_sample, work0, n, out, sample_buf, count, lean_origin, pixel_aux);
 }
 void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, const float* d, const uint16_t* pixel, const uint32_t* sample_index,
                         uint32_t dimension, uint32_t n, PathBuffers out, float4* sample_buf, uint32_t* pixel_xy, unsigned* ctrl) {

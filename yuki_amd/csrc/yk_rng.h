@@ -182,6 +182,48 @@ YK_HD SamplerState sampler_start(const SamplerCfg& c, unsigned px, unsigned py, 
     pcg_advance_sample(s.rng, index, dim);  // == pcg_advance(index * 65536 + dim)
     return s;
 }
+// What the camera sample's sampler start and first 2-D draw derive from the PIXEL alone (every sample of the pixel shares it):
+// the PCG stream = SipHash-1-3 of the pixel, and the stratified sampler's hash of (pixel, dimension 0, seed).  k_pixel_sampler
+// computes them once per pixel; k_raygen then starts a sample with two SipHashes less.
+struct PixelSampler {
+    u64 stream;       // hash_pixel(px, py)
+    unsigned hash0;   // low word of hash_pixel_dim_seed(px, py, 0, seed) (stratified only)
+};
+YK_HD PixelSampler pixel_sampler(const SamplerCfg& c, unsigned px, unsigned py) {
+    PixelSampler p;
+    p.stream = hash_pixel(px, py);
+    p.hash0 = c.kind == 0 ? 0u : (unsigned)hash_pixel_dim_seed(px, py, 0u, c.seed);
+    return p;
+}
+// sampler_start(c, px, py, index, 0) followed by sampler_get_2d, from the pixel's values: same state, same draws
+YK_HD SamplerState sampler_start_camera(const SamplerCfg& c, const PixelSampler& ps, unsigned px, unsigned py, unsigned index, float& ux, float& uy) {
+    SamplerState s;
+    s.px = px;
+    s.py = py;
+    s.sample_index = index;
+    s.dimension = 2;
+    s.rng = pcg_new(c.seed, ps.stream);
+    pcg_advance_sample(s.rng, index, 0u);
+    if (c.kind == 0) {
+        ux = pcg_f32(s.rng);
+        uy = pcg_f32(s.rng);
+        return s;
+    }
+    const unsigned stratum = permutation_element(index, c.spp, ps.hash0);
+    unsigned x, y;
+    if (((c.nx & (c.nx - 1u)) | (c.ny & (c.ny - 1u))) == 0u) {
+        x = stratum & (c.nx - 1u);
+        y = stratum >> (31 - __builtin_clz(c.ny));
+    } else {
+        x = stratum % c.nx;
+        y = stratum / c.ny;
+    }
+    const float dx = c.jitter ? pcg_f32(s.rng) : 0.5f;
+    const float dy = c.jitter ? pcg_f32(s.rng) : 0.5f;
+    ux = ((float)x + dx) / (float)c.nx;
+    uy = ((float)y + dy) / (float)c.ny;
+    return s;
+}
 YK_HD float sampler_get_1d(const SamplerCfg& c, SamplerState& s) {
     if (c.kind == 0) {
         s.dimension += 1;
