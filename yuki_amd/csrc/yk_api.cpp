@@ -823,7 +823,7 @@ static yk_status ensure_work_buffers(yk_context* ctx, WorkSet& ws, size_t paths,
     HIP_TRY(ctx, ws.hit.ensure(paths * 4));
     HIP_TRY(ctx, ws.pend.ensure(paths * 16));
     HIP_TRY(ctx, ws.shC.ensure(paths * nl * 16));
-    HIP_TRY(ctx, ws.vis.ensure(paths * nl));
+    HIP_TRY(ctx, ws.vis.ensure(paths * YK_VIS_STRIDE(nl)));
     // two shadow queues: rays towards area lights / towards point, spot and distant lights
     HIP_TRY(ctx, ws.shO.ensure(paths * na * 16));
     HIP_TRY(ctx, ws.shD.ensure(paths * na * 16));

@@ -14,7 +14,7 @@
 //     hit[i]                       source triangle or -1             (trace -> shade)
 //     pend[i] = (rgb, kind << 29 | sample slot in the batch)  emission / background term   (shade -> accumulate)
 //     shO/shD/shC[i*n_lights+l]    NEE shadow ray + its contribution (shade -> shadow -> accumulate)
-//     vis[i*n_lights+l]            0 none, 1 pending/visible, 2 occluded
+//     vis[i*VS+l]                  0 none, 1 pending/visible, 2 occluded; VS = YK_VIS_STRIDE(n_lights): 4 bytes per path for up to 4 lights
 //     shq[k]                       compacted list of pending shadow slots
 //   per chunk:
 //     sample_buf[sample_id] = (L.r, L.g, L.b, -)    radiance of one camera sample (Path: first written by k_accumulate of the camera bounce)
@@ -40,6 +40,8 @@ struct DevNode {
 };
 static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
 
+// stride of a path's verdict bytes in vis[]: up to four lights share one aligned word (one store in k_shade, one load in k_accumulate)
+#define YK_VIS_STRIDE(nl) ((nl) <= 4u ? 4u : (nl))
 #define YK_LEAF_BIT 0x80000000u
 #define YK_REF_NONE 0xffffffffu
 #define YK_AXIS_SHIFT 28

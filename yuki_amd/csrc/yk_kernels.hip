@@ -374,8 +374,11 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
         YK_PROF_STAMP(2)
         // ---- next-event estimation over ALL lights (path.rs:102-119); two sampler
         // dimensions are consumed per light whether or not it contributes.
+        // verdict bytes of a path: up to four lights share one word (written once after the loop, read once by k_accumulate)
+        const unsigned vs = YK_VIS_STRIDE(nl);
+        unsigned vword = 0u;
         for (unsigned l = 0; l < nl; ++l) {
-            unsigned slot = i * nl + l;
+            const unsigned slot = i * nl + l, vslot = i * vs + l;  // contribution slot / verdict byte (what the shadow queue carries)
             NeeSample ne;
             ne.want = false;
             ne.contrib = RGB{0, 0, 0};
@@ -384,7 +387,10 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
             ne.al = -1;
             if (valid && hit) ne = vertex_light(sc, prm, st, l, v);
             const bool want = ne.want;
-            if (valid) vis[slot] = want ? 1 : 0;
+            if (vs == 4u)
+                vword |= (want ? 1u : 0u) << (8u * l);
+            else if (valid)
+                vis[vslot] = want ? 1 : 0;
             // shadow rays are appended densely (coalesced for the any-hit kernel); the
             // contribution stays at its (path, light) slot for `accumulate`
             if (!per_iter) {
@@ -399,10 +405,11 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
             if (want) {
                 stg.qO[q] = make_float4(ne.so.x, ne.so.y, ne.so.z, 0.9999f);
                 stg.qD[q] = make_float4(ne.sd.x, ne.sd.y, ne.sd.z, __uint_as_float((unsigned)ne.al));
-                stg.qS[q] = slot;
+                stg.qS[q] = vslot;
                 shC[slot] = make_float4(ne.contrib.r, ne.contrib.g, ne.contrib.b, 0.0f);
             }
         }
+        if (vs == 4u && valid) reinterpret_cast<unsigned*>(vis)[i] = vword;
         YK_PROF_STAMP(3)
         if (valid) {
             unsigned kind = 0;
@@ -477,9 +484,12 @@ __global__ void k_accumulate(RenderParams prm, PathBuffers cur, const float4* pe
         }
         RGB radiance = RGB{0.0f, 0.0f, 0.0f};
         if (!(kind & YK_PEND_MISS)) {
+            const unsigned vs = YK_VIS_STRIDE(nl);
+            const unsigned vword = vs == 4u ? reinterpret_cast<const unsigned*>(vis)[i] : 0u;  // the verdicts of up to four lights in one word
             for (unsigned l = 0; l < nl; ++l) {
-                unsigned slot = i * nl + l;
-                if (vis[slot] == 1) {
+                const unsigned slot = i * nl + l;
+                const unsigned verdict = vs == 4u ? (vword >> (8u * l)) & 255u : (unsigned)vis[i * vs + l];
+                if (verdict == 1u) {
                     float4 ct = shC[slot];
                     radiance = radiance + RGB{ct.x, ct.y, ct.z};
                 }
