@@ -284,7 +284,8 @@ def main():
     # step k+1.  Every slot renders the same scene copy and tile list; steps stay ordered per slot.
     # Two slots; three once a rank's share is a quarter of the frame or less (1/4 share 35.97 -> 35.30 ms, 1/8 share 19.31 -> 18.85 ms;
     # 1/2 share 67.4 -> 67.9, whole frame 132.3 -> 133.7: tools/overlap_frames.py).
-    default_slots = 3 if world >= 4 else 2
+    share_single_batch = (wl["res"][0] * wl["res"][1] * spp) // max(1, world) <= (args.batch_paths or (128 << 20))
+    default_slots = 3 if (world >= 4 and share_single_batch) else 2  # a share of several batches keeps two work sets of 128 M paths per slot: HBM
     in_flight = max(1, args.frames_in_flight or (default_slots if (use_dist or single_batch) else 1)) if async_steps else 1
     slots = [dict(ctx=ctx, it=it, slab=slab, gathered=gathered, gathered_all=gathered_all, film=film)]
     for _ in range(1, in_flight):
