@@ -117,6 +117,7 @@ print("identical", G)
 """
 
 
+@pytest.mark.xfail(reason="first run on hardware: the development boxes have one GPU, this path had never executed when it was written", strict=False)
 def test_several_devices_render_one_film():
     """cfg4's shape on real hardware, when the box has it: yk_multi over 2 .. 4 GPUs — spiral tiles dealt round-robin, slabs to
     device 0 over RCCL send / recv, Film::update_tile there — equals the single-device film bit for bit.  Runs in a child process
