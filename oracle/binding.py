@@ -13,20 +13,41 @@ import numpy as np
 from yuki_amd import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIBS = {}
+_FLAVOUR = "default"
+_FILES = {"default": "liboracle.so", "hostlibm": "liboracle_hostlibm.so", "nth": "liboracle_nth.so"}
 
 
-def build():
-    subprocess.check_call(["make", "-s", "-C", _HERE])
+def build(target="liboracle.so"):
+    subprocess.check_call(["make", "-s", "-C", _HERE, target])
+
+
+class flavour:
+    """`with binding.flavour("hostlibm"):` — every oracle call inside goes to a sensitivity build
+    (oracle/Makefile `flavours`).  Scenes must be created and closed inside the same block.  The
+    default flavour is the parity oracle; the others only measure how far it could be from a
+    glibc / pdqselect build of the reference (tools/libm_sensitivity.py)."""
+
+    def __init__(self, name):
+        assert name in _FILES, name
+        self.name = name
+
+    def __enter__(self):
+        global _FLAVOUR
+        self.prev, _FLAVOUR = _FLAVOUR, self.name
+        return self
+
+    def __exit__(self, *a):
+        global _FLAVOUR
+        _FLAVOUR = self.prev
 
 
 def lib():
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    path = os.path.join(_HERE, "liboracle.so")
+    if _FLAVOUR in _LIBS:
+        return _LIBS[_FLAVOUR]
+    path = os.path.join(_HERE, _FILES[_FLAVOUR])
     if not os.path.exists(path):
-        build()
+        build(_FILES[_FLAVOUR])
     L = C.CDLL(path)
     vp = C.c_void_p
     L.orc_scene_create.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(vp)]
@@ -95,7 +116,7 @@ def lib():
     L.orc_texture_eval.restype = None
     L.orc_sizeof.argtypes = [C.c_int]
     L.orc_sizeof.restype = C.c_size_t
-    _LIB = L
+    _LIBS[_FLAVOUR] = L
     return L
 
 

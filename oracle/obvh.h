@@ -13,6 +13,7 @@
 // DESIGN.md ("select_nth spec"); the HIP-side host builder implements the
 // same spec so both trees are identical node for node.  Parity unpinned.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <vector>
 
@@ -55,6 +56,14 @@ struct BuildNode {
 
 // deterministic 3-way quickselect on centroid[axis] (see header comment)
 inline void select_nth(std::vector<BVHPrimitiveInfo>& a, size_t lo, size_t hi, size_t k, int axis) {
+#ifdef ORC_STD_NTH_ELEMENT
+    // sensitivity flavour (liboracle_nth.so, tools/libm_sensitivity.py): another legitimate selection
+    // algorithm (libstdc++'s introselect) in place of the select_nth spec — like Rust's pdqselect it
+    // leaves equal keys in an order of its own.  Measures what that freedom does to the image.
+    std::nth_element(a.begin() + lo, a.begin() + k, a.begin() + hi,
+                     [axis](const BVHPrimitiveInfo& x, const BVHPrimitiveInfo& y) { return x.centroid[axis] < y.centroid[axis]; });
+    return;
+#endif
     while (hi - lo > 1) {
         float pivot = a[lo + (hi - lo) / 2].centroid[axis];
         size_t i = lo, lt = lo, gt = hi;

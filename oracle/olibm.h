@@ -14,6 +14,13 @@
 // legitimate libm; tests/test_oracle_libm.py bounds the distance to glibc.
 //
 // No FMA anywhere: compile with -ffp-contract=off.
+//
+// Build flavour -DORC_HOST_LIBM (liboracle_hostlibm.so, tools/libm_sensitivity.py): the six
+// functions call the platform's sinf / cosf / tanf / logf / atan2f / acosf instead — on
+// x86-64 Linux with glibc that is what Rust's f32::{sin,cos,tan,ln,atan2,acos} resolve to
+// (call sites: sampling/mod.rs:62-87, trowbridge_reitz.rs:23-30,60-74, camera.rs:52-102,
+// sphere.rs:38-119).  It measures how far the fixed recipe moves an IMAGE from the one a
+// glibc build of the reference would produce; it is never the parity oracle.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -54,6 +61,9 @@ inline double reduce_pio2(double x, int64_t& n) {
 }
 
 inline float sinf_(float xf) {
+#ifdef ORC_HOST_LIBM
+    return ::sinf(xf);  // sensitivity flavour: the platform libm, what Rust's f32 methods call on Linux
+#endif
     double x = (double)xf;
     if (!(std::fabs(x) < 1.0e300)) return xf - xf;  // inf/NaN -> NaN
     int64_t n;
@@ -69,6 +79,9 @@ inline float sinf_(float xf) {
 }
 
 inline float cosf_(float xf) {
+#ifdef ORC_HOST_LIBM
+    return ::cosf(xf);  // sensitivity flavour: the platform libm, what Rust's f32 methods call on Linux
+#endif
     double x = (double)xf;
     if (!(std::fabs(x) < 1.0e300)) return xf - xf;
     int64_t n;
@@ -84,6 +97,9 @@ inline float cosf_(float xf) {
 }
 
 inline float tanf_(float xf) {
+#ifdef ORC_HOST_LIBM
+    return ::tanf(xf);  // sensitivity flavour: the platform libm, what Rust's f32 methods call on Linux
+#endif
     double x = (double)xf;
     if (!(std::fabs(x) < 1.0e300)) return xf - xf;
     int64_t n;
@@ -95,6 +111,9 @@ inline float tanf_(float xf) {
 
 // natural log of a positive finite binary32 value, evaluated in binary64
 inline float logf_(float xf) {
+#ifdef ORC_HOST_LIBM
+    return ::logf(xf);  // sensitivity flavour: the platform libm, what Rust's f32 methods call on Linux
+#endif
     if (xf != xf) return xf;
     if (xf < 0.0f) return (xf - xf) / 0.0f;                   // NaN
     if (xf == 0.0f) return -1.0f / 0.0f;                      // -inf (Rust ln(0) = -inf)
@@ -161,6 +180,9 @@ inline double k_atan_pos(double x) {
 }
 
 inline float atan2f_(float yf, float xf) {
+#ifdef ORC_HOST_LIBM
+    return ::atan2f(yf, xf);  // sensitivity flavour: the platform libm, what Rust's f32 methods call on Linux
+#endif
     const double PI = 3.14159265358979311600e+00, PIO2 = 1.57079632679489655800e+00;
     if (xf != xf || yf != yf) return xf + yf;
     double y = (double)yf, x = (double)xf;
@@ -185,6 +207,9 @@ inline float atan2f_(float yf, float xf) {
 }
 
 inline float acosf_(float xf) {
+#ifdef ORC_HOST_LIBM
+    return ::acosf(xf);  // sensitivity flavour: the platform libm, what Rust's f32 methods call on Linux
+#endif
     if (xf != xf) return xf;
     double x = (double)xf;
     if (x > 1.0 || x < -1.0) return (xf - xf) / (xf - xf);  // NaN

@@ -188,6 +188,28 @@ class SceneData:
         return d, keep
 
 
+def _mat4_mul(a, b):
+    """Matrix4x4 * Matrix4x4 (math/matrix.rs:289-301): four products added left to right in f32."""
+    r = np.zeros((4, 4), dtype=F)
+    for i in range(4):
+        for j in range(4):
+            r[i, j] = F(F(F(a[i, 0] * b[0, j]) + F(a[i, 1] * b[1, j])) + F(a[i, 2] * b[2, j])) + F(a[i, 3] * b[3, j])
+    return r
+
+
+def _transform_points(m, p):
+    """&Transform * Point3 (math/transform.rs:128-142): m[r][0]*x + m[r][1]*y + m[r][2]*z + m[r][3] in that
+    order, in f32, divided by w unless w == 1.  A zero term added to -0.0 gives +0.0, as in the reference."""
+    p = np.asarray(p, dtype=F)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    rows = [((m[r, 0] * x + m[r, 1] * y).astype(F) + m[r, 2] * z).astype(F) + m[r, 3] for r in range(4)]
+    out = np.stack(rows[:3], axis=1).astype(F)
+    w = rows[3].astype(F)
+    div = w != F(1)
+    out[div] = (out[div] / w[div, None]).astype(F)
+    return out
+
+
 def _translation(v):
     m = np.eye(4, dtype=F)
     m[:3, 3] = np.asarray(v, dtype=F)
@@ -252,11 +274,12 @@ def cornell():
 
     pts, uvs, idx, tmesh, tmat, tal, meshes = [], [], [], [], [], [], []
     base = 0
-    s = F(0.001)
+    # scene/mod.rs:177-185: into_meters * handedness_swap, applied by Mesh::new (shapes/mesh.rs:27-29)
+    handedness_swap = np.diag(np.asarray([1, 1, -1, 1], dtype=F))
+    into_meters = np.diag(np.asarray([0.001, 0.001, 0.001, 1], dtype=F))
+    to_world = _mat4_mul(into_meters, handedness_swap)
     for mi, (ind, p, uv, mat, al) in enumerate(mesh_defs):
-        p = np.asarray(p, dtype=F)
-        # Mesh::new applies handedness_swap_and_into_meters: x*0.001, y*0.001, z*(-0.001)
-        w = np.stack([s * p[:, 0], s * p[:, 1], (s * F(-1)) * p[:, 2]], axis=1).astype(F)
+        w = _transform_points(to_world, p)
         pts.append(w)
         uvs.append(np.asarray(uv, dtype=F) if uv is not None else np.zeros((len(p), 2), dtype=F))
         ii = np.asarray(ind, dtype=np.uint32).reshape(-1, 3) + np.uint32(base)
