@@ -1,9 +1,10 @@
-// yk_internal.h — library-private definitions shared by yk_api.cpp (single-device entry points) and
-// yk_multi.cpp (several devices of one process, RCCL): the objects behind the opaque handles of
-// include/yuki_hip.h.  Not installed.
+// yk_internal.h — library-private definitions shared by the host files of the library (yk_context.cpp,
+// yk_scene.cpp, yk_render.cpp, yk_stages.cpp: the single-device entry points; yk_multi.cpp: several devices of
+// one process, RCCL): the objects behind the opaque handles of include/yuki_hip.h.  Not installed.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -132,3 +133,61 @@ static inline yk_status fail(yk_context* ctx, yk_status st, const std::string& m
 struct SceneImage;
 yk_status yk_build_scene_image(yk_context* opt_ctx, const yk_scene_desc* d, std::shared_ptr<SceneImage>& out);
 yk_status yk_upload_scene_image(yk_context* ctx, const std::shared_ptr<SceneImage>& img, yk_scene** out);
+
+static inline double now_seconds() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------ yk_scene.cpp
+Material make_material(const yk_material_desc& m);  // per-hit constants folded (GGX alpha, Oren-Nayar A / B)
+DevLight make_light(const yk_light_desc& l);
+
+// ------------------------------------------------------------------ yk_render.cpp (used by yk_stages.cpp too)
+// ctx->counters: 8 x u64 (closest-hit rays, shadow rays, ...) followed by a 4-word error block whose word
+// YK_CTRL_ERR the traversal kernels set on a stack overflow.  Both are zeroed ONCE per call — the
+// per-batch control blocks of the work sets are zeroed with every batch and must not hold the flag.
+#define YK_COUNTER_BYTES 96
+unsigned* error_block(yk_context* ctx);
+yk_status ensure_work_buffers(yk_context* ctx, WorkSet& ws, size_t paths, unsigned n_lights, unsigned n_delta_lights);
+yk_status ensure_spill(yk_context* ctx, WorkSet& ws);
+unsigned trace_grid(const yk_context* ctx);
+PathBuffers path_buffers(WorkSet& ws, int which);
+yk_status make_params(yk_context* ctx, const yk_sampler_desc* smp, const yk_integrator_desc* integ, RenderParams& prm);
+
+struct KernelTimer {
+    yk_context* ctx;
+    bool on;
+    std::vector<std::pair<int, int>> spans[3];  // 0 trace, 1 shadow, 2 shade
+    size_t used = 0;
+    int begin(hipStream_t s) {
+        if (!on) return -1;
+        if (used + 2 > ctx->ev_pool.size()) {
+            size_t old = ctx->ev_pool.size();
+            ctx->ev_pool.resize(old + 256);
+            for (size_t i = old; i < ctx->ev_pool.size(); ++i) (void)hipEventCreate(&ctx->ev_pool[i]);
+        }
+        int a = (int)used;
+        used += 2;
+        (void)hipEventRecord(ctx->ev_pool[a], s);
+        return a;
+    }
+    void end(int a, int cls, hipStream_t s) {
+        if (a < 0) return;
+        (void)hipEventRecord(ctx->ev_pool[a + 1], s);
+        spans[cls].push_back(std::make_pair(a, a + 1));
+    }
+    double total(int cls) {
+        double ms = 0.0;
+        for (auto& sp : spans[cls]) {
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, ctx->ev_pool[sp.first], ctx->ev_pool[sp.second]) == hipSuccess) ms += t;
+        }
+        return ms * 1e-3;
+    }
+};
+
+bool packet_kernel_traces_bounce(const yk_context* ctx, const yk_scene* scene, unsigned b);
+// one batch of `n_paths` paths already generated into buffer 0; runs the bounce loop
+void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* scene, const RenderParams& prm, const uint32_t* pixel_xy,
+                 const uint32_t* sample_index_tab, float4* sample_buf, KernelTimer& kt, unsigned long long* counters, bool coherent,
+                 uint32_t n_paths, uint32_t sid_base, bool lean_camera_bounce, uint32_t* n_shadow_launches = nullptr);

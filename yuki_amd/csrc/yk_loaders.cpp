@@ -12,8 +12,8 @@
 // ignored, matte sigma goes through to_radians twice, TransformEnd pops the
 // graphics-state stack, unknown directives (Transform, ConcatTransform, Identity,
 // ...) abort the load.  Where the reference panics we return an error.
-// Image textures (Texture "imagemap") are not supported yet: the directive is
-// skipped and a matte material that references it fails like a missing texture.
+// Texture "spectrum" "imagemap" loads the file through yk_image_texture_load (yk_image.cpp) and a
+// matte Kd may name it (scene/pbrt/mod.rs:560-605, textures/image_texture.rs:66-141).
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
