@@ -13,7 +13,7 @@
 // graphics-state stack, unknown directives (Transform, ConcatTransform, Identity,
 // ...) abort the load.  Where the reference panics we return an error.
 // Texture "spectrum" "imagemap" loads the file through yk_image_texture_load (yk_image.cpp) and a
-// matte Kd may name it (scene/pbrt/mod.rs:560-605, textures/image_texture.rs:66-141).
+// matte Kd may name it (scene/pbrt/mod.rs:719-735, textures/image_texture.rs:66-141).
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
