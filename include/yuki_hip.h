@@ -201,9 +201,19 @@ typedef struct yk_render_stats {
 typedef struct yk_context yk_context;
 typedef struct yk_scene yk_scene;
 
-/* early_termination_predicate (integrators/mod.rs:129): polled between batches;
- * returning non-zero aborts the render with YK_ERR_CANCELLED (tile contents
- * undefined, as in render_worker.rs:252-255). */
+/* early_termination_predicate (integrators/mod.rs:129,153: the reference polls it once per pixel
+ * sample; render_worker.rs:240-255 relies on that for "low latency kills").  Returning non-zero
+ * aborts the render with YK_ERR_CANCELLED (tile contents undefined, as in render_worker.rs:252-255).
+ * When is it polled:
+ *   - before every batch is enqueued (all calls);
+ *   - in a SYNCHRONOUS call — one that returns pixels to the host or is given `stats` — about every
+ *     100 us while the GPU works.  On a non-zero answer a word in pinned host memory is set that the
+ *     persistent traversal kernels read whenever they claim work and k_shade once per window of
+ *     2048 vertices; they stop, every kernel still enqueued finds its queue empty, and the call
+ *     returns after the drain (a few ms).  The next render on the context is unaffected.
+ *   - an ASYNCHRONOUS submission (device output, stats == NULL) has returned before the GPU
+ *     started: the caller interrupts it with yk_context_interrupt from any thread.
+ * The predicate is called from the thread that made the call, never concurrently. */
 typedef int (*yk_cancel_fn)(void* user);
 
 /* ---- library / context ---------------------------------------------------- */
@@ -218,6 +228,10 @@ yk_status yk_last_error(const yk_context* ctx, char* buf, size_t cap);
  * without a second stream: wrap the handle (torch.cuda.ExternalStream, hipStreamWaitEvent ...).
  * Owned by the context; NULL for a NULL context. */
 void* yk_context_stream(const yk_context* ctx);
+/* Stop what the context has enqueued (see yk_cancel_fn): callable from any thread while another one is
+ * inside a render call on the same context.  Kernels stop at their next look at the word; the context's next
+ * submission first waits for the interrupted one to drain. */
+yk_status yk_context_interrupt(yk_context* ctx);
 /* tuning knobs (none changes any result): "batch_paths" (camera samples per batch, 64 .. 2^29),
  * "streams" (1|2 work sets), "sample_buf_cap" (bytes), "time_kernels" (0 | 1: per-kernel
  * seconds in yk_render_stats for jobs of at least 2^20 samples | 2: always),
@@ -323,6 +337,13 @@ yk_status yk_render_tiles_accumulating_passes(yk_context* ctx, const yk_scene* s
 yk_status yk_render_tile_list_passes_device(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
                                             const yk_integrator_desc* integrator, const yk_tile_list* list, uint32_t n_passes, void* d_out_rgb,
                                             void* stream, yk_render_stats* stats, yk_cancel_fn cancel, void* user);
+/* The same for a PLAIN tile list (tile_samples == NULL) whose tiles all stand at the same sample: passes first_sample ..
+ * first_sample + n_passes - 1 of every tile — the worker's accumulate loop (render_manager.rs:125-143 re-queues all
+ * tiles with the next sample index) without a new list per pass. */
+yk_status yk_render_tile_list_samples_device(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                             const yk_integrator_desc* integrator, const yk_tile_list* list, uint32_t first_sample,
+                                             uint32_t n_passes, void* d_out_rgb, void* stream, yk_render_stats* stats, yk_cancel_fn cancel,
+                                             void* user);
 yk_status yk_film_accumulate_tile_list_passes_device(yk_context* ctx, const yk_tile_list* list, const void* d_passes_rgb, uint32_t n_passes,
                                                      uint16_t res_x, uint16_t res_y, void* d_film_rgb, void* stream);
 
@@ -406,13 +427,29 @@ typedef struct yk_multi_film yk_multi_film;
 /* devices: HIP ordinals, devices[0] assembles the film.  n_devices == 1 is a plain one-GPU
  * render through the same code (no communicator unless "rccl_loopback" is set). */
 yk_status yk_multi_create(const int* devices, uint32_t n_devices, yk_multi** out);
+/* The same with flags:
+ *   YK_MULTI_PEER_COPY       the slabs travel by hipMemcpyPeerAsync on device 0's stream (behind an event of the
+ *                            sender's stream) instead of RCCL send / recv — no RCCL needed; also option "peer_copy";
+ *   YK_MULTI_SHARED_DEVICES  ranks may name the same device (RCCL refuses two ranks on one device, so this implies
+ *                            the peer copy): G ranks on ONE GPU run the deal, the per-rank tile lists, the slab
+ *                            layout, the exchange ordering and device 0's scatter exactly as G GPUs would — what a
+ *                            one-GPU box can test of the G > 1 path (tests/test_multi_gpu.py). */
+#define YK_MULTI_SHARED_DEVICES 1u
+#define YK_MULTI_PEER_COPY 2u
+yk_status yk_multi_create_ex(const int* devices, uint32_t n_devices, uint32_t flags, yk_multi** out);
+/* The deal, without a device: the tiles of `rank` among `n_ranks` — spiral tile i of film_tiles(res, tile_dim)
+ * (film.rs:333-376, 409-475) goes to rank i mod n_ranks (render_manager.rs:206-210).  Returns the number of tiles
+ * of the rank (0 on a bad argument), writes up to `cap` of them to `out` (may be NULL) and the rank's pixel count
+ * to *out_pixels (may be NULL): its slab holds 3 x that many floats, tile after tile, rows top to bottom. */
+size_t yk_multi_deal(uint16_t res_x, uint16_t res_y, uint16_t tile_dim, uint32_t n_ranks, uint32_t rank, yk_tile* out, size_t cap,
+                     uint64_t* out_pixels);
 /* Destroy the films and scenes made from it first or afterwards, in any order; a render must not be in flight. */
 void yk_multi_destroy(yk_multi* m);
 uint32_t yk_multi_device_count(const yk_multi* m);
 /* The context of rank r (options, yk_last_error); owned by the yk_multi. */
 yk_context* yk_multi_context(yk_multi* m, uint32_t rank);
 /* yk_context_set_option on every context; plus "rccl_loopback" (0 | 1): rank 0's own slab also
- * takes the ncclSend/ncclRecv path (to itself) — exercises the collective on a single GPU. */
+ * takes the exchange path (to itself) — exercises the collective on a single GPU; "peer_copy" (0 | 1). */
 yk_status yk_multi_set_option(yk_multi* m, const char* key, int64_t value);
 yk_status yk_multi_last_error(const yk_multi* m, char* buf, size_t cap);
 /* BoundingVolumeHierarchy::new once, one copy per device. */
@@ -428,17 +465,33 @@ void* yk_multi_film_device_ptr(const yk_multi_film* film);
 /* Render the whole film.  film_rgb: host buffer (res_x * res_y * 3 floats) or NULL; stats: sums
  * over the devices (seconds: the slowest device) or NULL.  With both NULL the call only
  * enqueues work (renders, exchange, scatter) and returns: yk_multi_sync waits for it, after
- * which yk_multi_film_device_ptr holds the frame.  cancel is polled by every device's render. */
+ * which yk_multi_film_device_ptr holds the frame.
+ * cancel: the user's predicate is never called concurrently and never again after it returned non-zero — the
+ * reference's is a consuming FnMut polled by one thread (render_worker.rs:240-249) — although every device's host
+ * thread polls: they share a latch, and the first non-zero answer stops ALL devices (YK_ERR_CANCELLED).  With a
+ * predicate the per-device renders are synchronous (it is polled about every 100 us while the GPUs work, see
+ * yk_cancel_fn); the film then holds nothing defined. */
 yk_status yk_multi_render_film(yk_multi* m, const yk_multi_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
                                const yk_integrator_desc* integrator, yk_multi_film* film, float* film_rgb, yk_render_stats* stats,
                                yk_cancel_fn cancel, void* user);
+/* The accumulating film over all devices (integrators/mod.rs:146-161 accumulating = true + film.rs:260-272): passes
+ * first_sample .. first_sample + n_passes - 1 of EVERY tile in one submission, each added to the film on device 0 —
+ * bit for bit the film n_passes single-device submissions produce.  yk_multi_film_clear zeroes the film (a new
+ * accumulation: FilmSettings.clear), stream-ordered on device 0. */
+yk_status yk_multi_accumulate_film(yk_multi* m, const yk_multi_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                   const yk_integrator_desc* integrator, yk_multi_film* film, uint32_t first_sample, uint32_t n_passes,
+                                   float* film_rgb, yk_render_stats* stats, yk_cancel_fn cancel, void* user);
+yk_status yk_multi_film_clear(yk_multi* m, yk_multi_film* film);
 yk_status yk_multi_sync(yk_multi* m);
 
 /* One process per GPU (MPI-style hosts, torch.distributed launchers): the same exchange between
  * processes.  Rank 0 obtains an id (ncclGetUniqueId) and hands it to the other ranks by its own
  * means; every rank then joins with its context (ncclCommInitRank).  yk_dist_gather moves
  * `count` floats from every rank's d_send into rank 0's d_recv[rank * count ...] on `stream`
- * (NULL: the context's stream), without host synchronisation; d_recv is ignored elsewhere. */
+ * (NULL: the context's stream), without host synchronisation; d_recv is ignored elsewhere.
+ * `count` MUST be the same on every rank (the padded maximum of the slab sizes: a rank's send and rank 0's
+ * receive are matched by count, unequal values hang the exchange).  The RCCL found at run time must report a 2.x
+ * version >= 2.7 (ncclGetVersion), anything else is YK_ERR_UNSUPPORTED. */
 #define YK_DIST_ID_BYTES 128
 typedef struct yk_dist yk_dist;
 yk_status yk_dist_unique_id(uint8_t id[YK_DIST_ID_BYTES]);

@@ -45,3 +45,11 @@ def ctx(yk):
     c = yk.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(scope="session")
+def cfg3_scene():
+    """BASELINE configs[2]'s scene (1,024,012 triangles), generated once per session; read-only."""
+    from yuki_amd import scenes
+
+    return scenes.by_name("cfg3")

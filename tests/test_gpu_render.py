@@ -340,12 +340,12 @@ def test_render_one_tile_accumulating(ctx, yk, oracle):
     assert rays == wrays and np.array_equal(_bits(got), _bits(want))
 
 
-def test_bench_workload_at_full_size(ctx, yk, oracle):
+def test_bench_workload_at_full_size(ctx, yk, oracle, cfg3_scene):
     """BASELINE config 3 exactly as bench.py runs it (1,024,012 triangles, SAH BVH, Path 8,
     Stratified 8x8, 1920x1080): (1) the first 96 spiral tiles at full spp against the oracle,
     bit for bit; (2) size-independent properties of the whole frame — the shard of rank 3 of 8
     equals the same tiles of the full render, and the ray count is the sum over shards."""
-    sd = scenes.by_name("cfg3")
+    sd = cfg3_scene
     fs = yk.FilmSettings(res=(1920, 1080), tile_dim=16)
     cam = yk.Camera(sd.camera, fs)
     tiles = yk.film_tiles(fs)
@@ -373,6 +373,72 @@ def test_bench_workload_at_full_size(ctx, yk, oracle):
         assert np.array_equal(_bits(shard), _bits(ref))
         total += st.rays
     assert 0.11 < total / st_full.rays < 0.14
+
+
+def test_cancellation_at_the_references_granularity(yk, cfg3_scene):
+    """integrators/mod.rs:153 polls the predicate once per pixel sample and render_worker.rs:240-255 relies on it for "low
+    latency kills".  A cfg5-sized job (3840x2160 x 256 spp, Path 16: sixteen batches of 128 M camera samples, ~1.5 s) on the
+    cfg3 scene is cancelled 50 ms after it started: the call returns YK_ERR_CANCELLED a few milliseconds after the predicate
+    fired (kernels stop at their next work claim / shade window, what is still enqueued finds empty queues), and the NEXT render
+    on the same context equals a fresh context's bit for bit.  yk_context_interrupt from another thread does the same."""
+    import threading
+    import time
+
+    sd = cfg3_scene
+    big = yk.FilmSettings(res=(3840, 2160), tile_dim=16)
+    big_sampler = yk.SamplerType.Stratified((16, 16), True, SEED)
+    big_integ = yk.IntegratorType.Path(yk.PathParams(max_depth=16))
+    small = yk.FilmSettings(res=(320, 180), tile_dim=16)
+    small_sampler = yk.SamplerType.Stratified((4, 4), True, SEED)
+    small_integ = yk.IntegratorType.Path(yk.PathParams(max_depth=8))
+    fresh = yk.Context(0)
+    fsc = yk.Scene(fresh, sd)
+    want, st_want = yk.IntegratorType.instantiate(fresh, small_integ).render_tiles(fsc, yk.Camera(sd.camera, small), small_sampler, yk.film_tiles(small))
+    c = yk.Context(0)
+    sc = yk.Scene(c, sd)
+    it = yk.IntegratorType.instantiate(c, big_integ)
+    cam = yk.Camera(sd.camera, big)
+    tiles = yk.film_tiles(big)
+    it.render_tiles(sc, yk.Camera(sd.camera, small), small_sampler, yk.film_tiles(small))  # buffers and code objects exist before the clock starts
+    latencies = []
+    for delay in (0.050, 0.200):
+        t0 = time.time()
+        fired = []
+
+        def pred():
+            if not fired and time.time() - t0 >= delay:
+                fired.append(time.time())
+                return True
+            return False
+
+        with pytest.raises(yk.YukiError) as e:
+            it.render_tiles(sc, cam, big_sampler, tiles, cancel=pred)
+        t1 = time.time()
+        assert e.value.status == 7 and fired  # YK_ERR_CANCELLED
+        latencies.append(t1 - fired[0])
+        got, st = yk.IntegratorType.instantiate(c, small_integ).render_tiles(sc, yk.Camera(sd.camera, small), small_sampler, yk.film_tiles(small))
+        assert st.rays == st_want.rays and np.array_equal(_bits(got), _bits(want))
+    print("cancel latencies (predicate fired -> call returned):", ["%.1f ms" % (1e3 * x) for x in latencies])
+    assert max(latencies) < 0.040, latencies  # measured 3-8 ms; the whole job takes ~1.5 s
+    # the same from another thread, for a caller without a predicate
+    timer = threading.Timer(0.050, c.interrupt)
+    t0 = time.time()
+    timer.start()
+    full_st = None
+    try:
+        _, full_st = it.render_tiles(sc, cam, big_sampler, tiles)
+    except yk.YukiError as err:  # the synchronous call notices that its work was interrupted
+        assert err.status == 7
+    dt = time.time() - t0
+    timer.join()
+    assert dt < 0.5, dt
+    assert full_st is None
+    got, st = yk.IntegratorType.instantiate(c, small_integ).render_tiles(sc, yk.Camera(sd.camera, small), small_sampler, yk.film_tiles(small))
+    assert st.rays == st_want.rays and np.array_equal(_bits(got), _bits(want))
+    sc.close()
+    fsc.close()
+    c.close()
+    fresh.close()
 
 
 def test_max_depth_zero_renders_black(ctx, yk, oracle):

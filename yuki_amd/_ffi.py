@@ -116,12 +116,18 @@ SYMBOLS = {
     "yk_render_tile_list_device": (C.c_int, [vp, vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), vp, vp, vp, C.POINTER(RenderStats), vp, vp]),
     "yk_film_update_tile_list_device": (C.c_int, [vp, vp, vp, C.c_uint16, C.c_uint16, vp, vp, C.c_int]),
     "yk_render_tiles_accumulating_passes": (C.c_int, [vp, vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), vp, vp, C.c_size_t, C.c_uint32, vp, C.POINTER(RenderStats), vp, vp]),
+    "yk_render_tile_list_samples_device": (C.c_int, [vp, vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), vp, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(RenderStats), vp, vp]),
     "yk_render_tile_list_passes_device": (C.c_int, [vp, vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), vp, C.c_uint32, vp, vp, C.POINTER(RenderStats), vp, vp]),
     "yk_film_accumulate_tile_list_passes_device": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint16, C.c_uint16, vp, vp]),
     "yk_write_exr": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, vp]),
     "yk_write_pfm": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, vp]),
     # several GPUs
     "yk_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_uint32, C.POINTER(vp)]),
+    "yk_multi_create_ex": (C.c_int, [C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+    "yk_multi_deal": (C.c_size_t, [C.c_uint16, C.c_uint16, C.c_uint16, C.c_uint32, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "yk_multi_accumulate_film": (C.c_int, [vp, vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), vp, C.c_uint32, C.c_uint32, vp, C.POINTER(RenderStats), vp, vp]),
+    "yk_multi_film_clear": (C.c_int, [vp, vp]),
+    "yk_context_interrupt": (C.c_int, [vp]),
     "yk_multi_destroy": (None, [vp]),
     "yk_multi_device_count": (C.c_uint32, [vp]),
     "yk_multi_context": (vp, [vp, C.c_uint32]),

@@ -60,6 +60,17 @@ def film_tiles(settings: FilmSettings):
     return t
 
 
+def multi_deal(settings: FilmSettings, n_ranks, rank):
+    """yk_multi_deal: the tiles of `rank` among `n_ranks` (spiral tile i -> rank i mod n_ranks, render_manager.rs:206-210)
+    and the rank's pixel count; needs no device."""
+    L = lib()
+    px = C.c_uint64(0)
+    n = L.yk_multi_deal(settings.res[0], settings.res[1], settings.tile_dim, n_ranks, rank, None, 0, C.byref(px))
+    t = np.zeros(n, dtype=abi.TILE_DTYPE)
+    L.yk_multi_deal(settings.res[0], settings.res[1], settings.tile_dim, n_ranks, rank, _p(t), n, C.byref(px))
+    return t, int(px.value)
+
+
 def update_tiles(tiles, tile_rgb, res):
     """Film::update_tile (film.rs:210-282) for a list of tiles: tile-major -> row-major."""
     tiles = np.ascontiguousarray(tiles, dtype=abi.TILE_DTYPE)
@@ -220,6 +231,10 @@ class Context:
     def set_option(self, key, value):
         check(lib().yk_context_set_option(self.h, key.encode(), int(value)), self.h)
 
+    def interrupt(self):
+        """yk_context_interrupt: stop what the context has enqueued (any thread)."""
+        check(lib().yk_context_interrupt(self.h))
+
     @property
     def stream_handle(self):
         """The context's hipStream_t as an integer (yk_context_stream): wrap it, e.g. with
@@ -314,11 +329,15 @@ class Multi:
     film's spiral are dealt round-robin (render_manager.rs:206-210), the slabs meet on devices[0]
     through RCCL and Film::update_tile runs there."""
 
-    def __init__(self, devices, **options):
+    SHARED_DEVICES, PEER_COPY = 1, 2  # yk_multi_create_ex flags
+
+    def __init__(self, devices, flags=0, **options):
+        """flags: Multi.SHARED_DEVICES — ranks may name the same device (G ranks on one GPU: what a one-GPU box can run of
+        the G > 1 path; the slabs travel by device copies); Multi.PEER_COPY — hipMemcpyPeerAsync instead of RCCL."""
         devices = [int(d) for d in devices]
         arr = (C.c_int * len(devices))(*devices)
         h = C.c_void_p()
-        check(lib().yk_multi_create(arr, len(devices), C.byref(h)))
+        check(lib().yk_multi_create_ex(arr, len(devices), int(flags), C.byref(h)) if flags else lib().yk_multi_create(arr, len(devices), C.byref(h)))
         self.h = h
         self.devices = devices
         for k, v in options.items():
@@ -344,6 +363,21 @@ class Multi:
             self.h,
         )
         return out, stats
+
+    def accumulate_film(self, scene, camera, sampler, integrator, film, first_sample, n_passes=1, want_host=True, want_stats=True, cancel=None):
+        """The accumulating film over all devices (yk_multi_accumulate_film): passes first_sample .. + n_passes - 1 of every
+        tile, each added to the film on device 0 (film.rs:260-272).  clear_film() starts a new accumulation."""
+        out = np.zeros((film.res[1], film.res[0], 3), dtype=np.float32) if want_host else None
+        stats = RenderStats() if want_stats else None
+        cb = _ffi.CANCEL_FN(lambda _u: 1 if cancel() else 0) if cancel else None
+        _mcheck(
+            lib().yk_multi_accumulate_film(self.h, scene.h, C.byref(camera.matrices), C.byref(sampler), C.byref(integrator), film.h, int(first_sample), int(n_passes), _p(out), C.byref(stats) if want_stats else None, C.cast(cb, C.c_void_p) if cb else None, None),
+            self.h,
+        )
+        return out, stats
+
+    def clear_film(self, film):
+        _mcheck(lib().yk_multi_film_clear(self.h, film.h), self.h)
 
     def sync(self):
         _mcheck(lib().yk_multi_sync(self.h), self.h)
@@ -509,6 +543,17 @@ class Integrator:
             self.ctx.h,
         )
         return stats
+
+    def render_tile_list_samples_device(self, scene, camera, sampler, tile_list, first_sample, n_passes, d_out_ptr, stream=None, want_stats=False, cancel=None):
+        """Passes first_sample .. first_sample + n_passes - 1 of every tile of a PLAIN tile list (the worker's accumulate loop,
+        render_manager.rs:125-143), pass-major into HBM at `d_out_ptr`."""
+        stats = RenderStats()
+        cb = _ffi.CANCEL_FN(lambda _u: 1 if cancel() else 0) if cancel else None
+        check(
+            lib().yk_render_tile_list_samples_device(self.ctx.h, scene.h, C.byref(camera.matrices), C.byref(sampler), C.byref(self.desc), tile_list.h, int(first_sample), int(n_passes), C.c_void_p(d_out_ptr), C.c_void_p(stream) if stream else None, C.byref(stats) if want_stats else None, C.cast(cb, C.c_void_p) if cb else None, None),
+            self.ctx.h,
+        )
+        return stats if want_stats else None
 
     def render_tile_list_device(self, scene, camera, sampler, tile_list, d_out_ptr, stream=None, want_stats=False, n_passes=1):
         """Render a prepared TileList into HBM at `d_out_ptr`; with want_stats=False the call only

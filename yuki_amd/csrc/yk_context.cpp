@@ -59,11 +59,30 @@ yk_status yk_context_create(int device, yk_context** out) {
         hipEventCreateWithFlags(&ctx->ws[0].ev_shade, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ws[1].ev_shade, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ws[0].ev_acc, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ws[1].ev_acc, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ws[1].ev_acc, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ws[0].ev_batch, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ws[1].ev_batch, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return YK_ERR_DEVICE;
     }
     ctx->ws[0].stream = ctx->stream;
+    // the interruption word the kernels poll (yk_device.h, CancelRef): pinned, mapped, coherent host memory.  Without it
+    // (allocation refused) renders still work and are interruptible between batches only.
+    void* host_word = nullptr;
+    if (hipHostMalloc(&host_word, 128, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        void* dev_word = nullptr;
+        if (hipHostGetDevicePointer(&dev_word, host_word, 0) == hipSuccess) {
+            ctx->cancel_host = static_cast<unsigned*>(host_word);
+            ctx->cancel_host_dev = static_cast<const unsigned*>(dev_word);
+            std::memset(host_word, 0, 128);
+            ctx->cancel_host[16] = 1u;
+            if (hipStreamCreateWithFlags(&ctx->cancel_stream, hipStreamNonBlocking) != hipSuccess) ctx->cancel_stream = nullptr;
+        } else {
+            (void)hipHostFree(host_word);
+        }
+    } else {
+        (void)hipGetLastError();
+    }
     if (const char* w = std::getenv("YK_WIDE_BVH")) ctx->wide_bvh = std::min(std::max(std::atoi(w), 0), 2);  // experiments; same as set_option("wide_bvh")
     if (const char* w = std::getenv("YK_PACKET_BOUNCES")) ctx->packet_bounces = std::max(std::atoi(w), 0);
     if (const char* w = std::getenv("YK_PACKET_SHADOW_BOUNCES")) ctx->packet_shadow_bounces = std::max(std::atoi(w), 0);
@@ -85,6 +104,7 @@ void yk_context_destroy(yk_context* ctx) {
         if (w.done) (void)hipEventDestroy(w.done);
         if (w.ev_shade) (void)hipEventDestroy(w.ev_shade);
         if (w.ev_acc) (void)hipEventDestroy(w.ev_acc);
+        if (w.ev_batch) (void)hipEventDestroy(w.ev_batch);
         if (w.side) {
             (void)hipStreamSynchronize(w.side);
             (void)hipStreamDestroy(w.side);
@@ -97,6 +117,11 @@ void yk_context_destroy(yk_context* ctx) {
     for (DevBuf* b : all) b->release();
     for (DevBuf& b : ctx->scratch) b.release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->cancel_stream) {
+        (void)hipStreamSynchronize(ctx->cancel_stream);
+        (void)hipStreamDestroy(ctx->cancel_stream);
+    }
+    if (ctx->cancel_host) (void)hipHostFree(ctx->cancel_host);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -159,6 +159,7 @@ struct PathBuffers {
 // points (yk_trace_closest / yk_trace_any) use word 0 as the ray count and YK_CTRL_HEADS as head.
 #define YK_CTRL_WORDS 1024
 #define YK_CTRL_ERR 3
+#define YK_CTRL_CANCELLED 2  // in the context's error block (yk_internal.h): CancelRef::dev
 // A float4 BEHIND the zeroed words (its own cache line: the words above are hammered by queue atomics): the camera's ray
 // origin, written by raygen.  The camera bounce of a Path render whose rays go to the wave-packet kernel is "lean": every
 // ray starts there with throughput one, so raygen stores neither rayO nor thru and the packet kernel, k_shade and
@@ -173,6 +174,34 @@ struct PathBuffers {
 #define YK_CTRL_HEAD 3  // + {0: closest, 1: any, 2: any (delta queue)}
 #define YK_CTRL_MAX_DEPTH ((YK_CTRL_WORDS - 8) / YK_CTRL_STRIDE - 1)
 
+// Interruption (integrators/mod.rs:153: the reference polls its predicate once per pixel sample).  Two words: `host` lives in
+// pinned host memory and is written by the host thread that polls the predicate; `dev` is a word in device memory that EVERY
+// queue-driven kernel reads when it starts — every block of it: k_shade's and k_accumulate's blocks live for a window or two of a
+// long launch — and then treats its queue as empty.  Who carries the
+// news from `host` to `dev`: (1) ONE wave of every persistent traversal launch — the first wave of block 0 — reads `host`
+// whenever it claims work (a PCIe round trip: every wave doing so halved the traversal rate), raises `dev` and poisons the
+// launch's queue head so that no wave claims again; (2) the host, with a 4-byte copy on a stream of its own.  Both words only ever
+// go from 0 to 1 during a submission, so a later kernel never sees less than an earlier one did: nothing reads what an
+// interrupted kernel left unwritten.  Null pointers: no interruption (per-stage entry points).
+struct CancelRef {
+    const unsigned* host;
+    unsigned* dev;
+};
+#define YK_HEAD_POISON 0xC0000000u  // above any queue length (< 2^31); 2^30 below the wrap, a wave claims at most once more
+
+// A kernel's look at `dev` when it starts: an ordinary (cached, scalar) load like the one of its queue length — whatever was
+// written before the launch began is visible to it.  (An agent-scope atomic load here, one per block of k_shade's 65,536, cost
+// 4 ms of 30 per frame: it goes to memory and the block's first barrier waits for it.)  Blocks that start later during a long
+// grid-stride launch usually see a word raised meanwhile as well; nothing depends on that.
+__device__ __forceinline__ bool cancel_raised(const CancelRef& c) { return c.dev && *c.dev != 0u; }
+// the relay wave's look at the host's word (one lane): raises `dev`, poisons `head`
+__device__ __forceinline__ bool cancel_relay(const CancelRef& c, unsigned* head) {
+    if (!c.host || __hip_atomic_load(c.host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) return false;
+    atomicOr(c.dev, 1u);
+    atomicMax(head, YK_HEAD_POISON);
+    return true;
+}
+
 struct RenderParams {
     SamplerCfg sampler;
     uint32_t max_depth;
@@ -183,6 +212,8 @@ struct RenderParams {
     // film: spe = spp and sample index = k.  With a sample-index table (accumulating film,
     // yk_li) the sample index is table[entry] + k; spe = the number of passes rendered at once.
     uint32_t spe;
+    uint32_t sample_base;  // sample index of an entry when there is no table: 0 for the plain film, FilmTile.sample shared by all tiles otherwise
+    CancelRef cancel;
 };
 
 // sample id -> (entry of the pixel table, sample within the entry): id = entry * spe + k.  `spe` is uniform and nearly always a

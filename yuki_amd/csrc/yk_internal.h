@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <memory>
 #include <mutex>
@@ -62,10 +63,18 @@ struct yk_context {
         hipStream_t stream = nullptr;
         hipStream_t side = nullptr;  // shadow rays + accumulate of bounce b run here beside trace of bounce b+1
         hipEvent_t done = nullptr, ev_shade = nullptr, ev_acc = nullptr;
+        hipEvent_t ev_batch = nullptr;  // end of the work set's latest batch (pacing of interruptible jobs, yk_render.cpp)
     } ws[2];
     DevBuf sample_buf, pixel_xy, pixel_aux, tiles, tile_off, counters, stats4, hit4, scratch[8];
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;  // hand-over between a caller's stream and the context's own
+    // Interruption (yk_device.h, CancelRef): cancel_host[0] is the word the kernels poll across PCIe (pinned, mapped, coherent host
+    // memory; cancel_host_dev is its device address); cancel_raised remembers that a submission left it set — the next one waits
+    // for the context's streams before it clears the word, so that no kernel of the interrupted submission resumes.
+    unsigned* cancel_host = nullptr;  // [0] the word, [16] a constant 1: the source of the host's copy into the device word
+    const unsigned* cancel_host_dev = nullptr;
+    hipStream_t cancel_stream = nullptr;  // carries that copy past the kernels in flight
+    std::atomic<bool> cancel_raised{false};
     // every entry point that touches the context's buffers or streams holds this: calls on one
     // context from several host threads (the reference's tile workers) are serialised
     std::recursive_mutex mu;
@@ -144,10 +153,13 @@ DevLight make_light(const yk_light_desc& l);
 
 // ------------------------------------------------------------------ yk_render.cpp (used by yk_stages.cpp too)
 // ctx->counters: 8 x u64 (closest-hit rays, shadow rays, ...) followed by a 4-word error block whose word
-// YK_CTRL_ERR the traversal kernels set on a stack overflow.  Both are zeroed ONCE per call — the
-// per-batch control blocks of the work sets are zeroed with every batch and must not hold the flag.
-#define YK_COUNTER_BYTES 96
+// YK_CTRL_ERR the traversal kernels set on a stack overflow and whose word YK_CTRL_CANCELLED says that the render was interrupted.
+// Both are zeroed ONCE per call — the per-batch control blocks of the work sets are zeroed with every batch and must not hold the flags.
+// The error block has a 128-byte line of its own: its word YK_CTRL_CANCELLED is read by every kernel that starts, the counters
+// before it take an atomic per wave.
+#define YK_COUNTER_BYTES 256
 unsigned* error_block(yk_context* ctx);
+CancelRef cancel_ref(yk_context* ctx);  // the context's interruption words, as the kernels take them
 yk_status ensure_work_buffers(yk_context* ctx, WorkSet& ws, size_t paths, unsigned n_lights, unsigned n_delta_lights);
 yk_status ensure_spill(yk_context* ctx, WorkSet& ws);
 unsigned trace_grid(const yk_context* ctx);

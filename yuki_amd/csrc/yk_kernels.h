@@ -14,9 +14,9 @@ unsigned trace_top_nodes_any();
 unsigned packet_blocks_per_cu();
 // rayO == nullptr: every ray starts at *lean_origin (the lean camera bounce, yk_device.h)
 void launch_trace_closest_packet(hipStream_t s, unsigned grid, const DevScene& sc, const float4* rayO, const float4* rayD, const unsigned* count_ptr,
-                                 unsigned* head, int* hit_tri, unsigned long long* ray_counter, const float4* lean_origin = nullptr);
+                                 unsigned* head, int* hit_tri, unsigned long long* ray_counter, const float4* lean_origin = nullptr, CancelRef cancel = CancelRef{nullptr, nullptr});
 void launch_trace_any_packet(hipStream_t s, unsigned grid, const DevScene& sc, const float4* shO, const float4* shD, const unsigned* slot_of,
-                             const unsigned* count_ptr, unsigned* head, unsigned char* vis, unsigned long long* shadow_counter);
+                             const unsigned* count_ptr, unsigned* head, unsigned char* vis, unsigned long long* shadow_counter, CancelRef cancel = CancelRef{nullptr, nullptr});
 unsigned trace_blocks_per_cu();
 
 void launch_pixel_table(hipStream_t s, const yk_tile* tiles, const uint32_t* tile_offset, uint32_t n_tiles, uint32_t n_pixels, uint32_t* pixel_xy,
@@ -29,13 +29,13 @@ void launch_raygen_user(hipStream_t s, const RenderParams& prm, const float* o, 
                         uint32_t dimension, uint32_t n, PathBuffers out, float4* sample_buf, uint32_t* pixel_xy, unsigned* ctrl);
 void launch_trace_closest(hipStream_t s, unsigned grid, const DevScene& sc, const float4* rayO, const float4* rayD, const float* t_max_opt,
                           const unsigned* count_ptr, unsigned* head, int* hit_tri, float4* hit_out, uint4* stats_out, uint2* spill,
-                          unsigned spill_stride, unsigned* ctrl, unsigned long long* ray_counter);
+                          unsigned spill_stride, unsigned* ctrl, unsigned long long* ray_counter, const unsigned* cancel_host = nullptr);
 void launch_whitted(hipStream_t s, unsigned grid, const DevScene& sc, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                     PathBuffers cur, uint32_t n, float4* sample_buf, uint2* spill, unsigned spill_stride, unsigned* ctrl, unsigned long long* counters);
 unsigned whitted_max_depth();
 void launch_trace_any(hipStream_t s, unsigned grid, const DevScene& sc, const float4* shO, const float4* shD, const unsigned* slot_of,
                       const unsigned* count_ptr, unsigned* head, unsigned char* vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
-                      unsigned long long* shadow_counter);
+                      unsigned long long* shadow_counter, const unsigned* cancel_host = nullptr);
 void launch_shade(hipStream_t s, unsigned grid, const DevScene& sc, const RenderParams& prm, const uint32_t* pixel_xy, const uint32_t* sample_index_tab,
                   PathBuffers cur, PathBuffers nxt, const int* hit_tri, float4* pend, float4* shO, float4* shD, float4* shC, unsigned char* vis,
                   unsigned* shq, float4* shO2, float4* shD2, unsigned* shq2, unsigned* bc, unsigned split_delta, unsigned reorder, unsigned block_slots, unsigned sid_base, const float4* lean_origin);

@@ -81,12 +81,13 @@ __device__ __forceinline__ void camera_ray(const DevCamera& cam, float fx, float
 __global__ void k_raygen(DevCamera cam, RenderParams prm, const uint32_t* pixel_xy, const uint32_t* pixel_sample, uint64_t work0, uint32_t n,
                          PathBuffers out, float4* sample_buf, unsigned* count, float4* lean_origin, const uint4* pixel_aux) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cancel_raised(prm.cancel)) return;  // *count stays zero (the batch's control block was cleared): every later kernel of the batch finds an empty queue
     if (i == 0) *count = n;
     if (i >= n) return;
     const uint32_t w = (uint32_t)(work0 + i);  // a chunk holds fewer than 2^32 samples (it indexes sample_buf)
     uint32_t pix, ks;
     split_sample_id(w, prm.spe, pix, ks);
-    const uint32_t s = (pixel_sample ? pixel_sample[pix] : 0u) + ks;
+    const uint32_t s = (pixel_sample ? pixel_sample[pix] : prm.sample_base) + ks;
     uint32_t xy = pixel_xy[pix];
     uint32_t px = xy & 0xffffu, py = xy >> 16;
     SamplerState st;
@@ -143,8 +144,9 @@ __global__ void k_raygen_user(RenderParams prm, const float* ray_o, const float*
 // "dequeue") and made this kernel atomic-bound (profiles/r01_a_*: 0.178 s/frame,
 // 79 % of wave cycles waiting).
 #ifndef SHADE_CAP
-#define SHADE_CAP 336  // staged continuation paths per block (64 B each).  With SHADE_CAPQ and the sort window's order table the block's LDS is
-                       // 53296 B: three blocks per CU (LDS is handed out in 1280-byte granules on gfx950: 53760 x 3 fits 160 KB, one granule more does not)
+#define SHADE_CAP 335  // staged continuation paths per block (64 B each).  With SHADE_CAPQ and the sort window's order table the block's LDS is
+                       // 53248 B: three blocks per CU.  The cliff was measured, not computed: 53296 B runs three blocks, 53312 B (one more
+                       // word, round 3's interruption flag) ran two and cost 4.6 ms of 30.6 per frame — hence 335, not 336
 #endif
 #ifndef SHADE_CAPQ
 #define SHADE_CAPQ 768  // staged shadow rays per block (36 B each): a whole iteration of 256 paths x 3 lights fits
@@ -162,6 +164,7 @@ template <int CAP, int CAPQ> struct ShadeStaging {
     unsigned qS[CAPQ];
     unsigned fill_p, fill_q, gbase;
     unsigned q_delta;  // class of the staged shadow rays: 1 = towards a point/spot/distant light
+    unsigned cancel;   // the render was interrupted (yk_device.h, CancelRef): block-uniform copy of what thread 0 read
     unsigned bucket[8];                  // material-kind histogram of the window's paths
     unsigned short order[SHADE_WIN * 256];  // sorted position -> offset of the path inside the window
 };
@@ -199,9 +202,8 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
     // iterations per window: a full queue sorts win_max (<= SHADE_WIN) x 256 paths together; a queue too short to give every
     // resident block (`block_slots` of them on the device) a full window takes shorter ones, down to one iteration
     const unsigned win_iters = min(win_max, max(1u, bc[0] / (BLOCK * block_slots)));
-    static_assert(sizeof(ShadeStaging<CAP, CAPQ>) <= 53760, "k_shade: more than 42 LDS granules per block costs the third block per CU");
+    static_assert(sizeof(ShadeStaging<CAP, CAPQ>) <= 53296, "k_shade: 53312 bytes of LDS per block were measured to cost the third block per CU");
     __shared__ ShadeStaging<CAP, CAPQ> stg;
-    const unsigned n = bc[0];
     const unsigned nl = sc.n_lights;
     unsigned* next_count = bc + YK_CTRL_STRIDE;
     unsigned* shq_count = bc + YK_CTRL_SHQ;
@@ -209,8 +211,14 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
         stg.fill_p = 0;
         stg.fill_q = 0;
         stg.q_delta = 0;
+        stg.cancel = cancel_raised(prm.cancel) ? 1u : 0u;
     }
     __syncthreads();
+    // an interrupted render: the queue counts as empty for the WHOLE block (the barriers below need block-uniform control flow,
+    // so the word is read by one thread and shared through LDS) and nothing is appended for the next bounce; a block lives for
+    // one or two windows of a long launch (the grid has 256 blocks per CU), so this is also the launch's look "per window".
+    // (readfirstlane: an LDS read is per-lane to the compiler, the queue length has to stay a scalar)
+    const unsigned n = __builtin_amdgcn_readfirstlane((int)stg.cancel) ? 0u : bc[0];
     // flush helpers (block-uniform control flow)
     // Shadow rays go to one of two queues: rays towards an area light leave a surface patch
     // in scattered directions, rays towards a point / spot / distant light converge on one
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
             uint32_t xy = pixel_xy[pix];
             st.px = xy & 0xffffu;
             st.py = xy >> 16;
-            st.sample_index = (sample_index_tab ? sample_index_tab[pix] : 0u) + ks;
+            st.sample_index = (sample_index_tab ? sample_index_tab[pix] : prm.sample_base) + ks;
             int tri = hit_tri[i];
             hit = tri >= 0;
             if (hit) vertex_setup(sc, (uint32_t)tri & YK_HIT_PRIM_MASK, o, d, v);  // the leaf-order slot reported by the render-loop trace kernels
@@ -467,7 +475,7 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
 // stored +0 included), so the slot is written without being read.
 __global__ void k_accumulate(RenderParams prm, PathBuffers cur, const float4* pend, const float4* shC, const unsigned char* vis, unsigned nl,
                              float4* sample_buf, const unsigned* bc, unsigned first, unsigned sid_base) {
-    const unsigned n = bc[0];
+    const unsigned n = cancel_raised(prm.cancel) ? 0u : bc[0];  // an interrupted k_shade left pending terms unwritten: nothing of this bounce is read
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 p = pend[i];
         const unsigned kind = __float_as_uint(p.w) >> YK_PEND_KIND_SHIFT;

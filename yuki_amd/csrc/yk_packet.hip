@@ -191,11 +191,11 @@ __device__ __forceinline__ void pkt_closest_group(const DevScene& sc, PktStack& 
 template <bool SPHERES>
 __global__ __launch_bounds__(YK_PKT_BLOCK, 8) void k_trace_closest_packet(DevScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
                                                                           const unsigned* count_ptr, unsigned* head, int* __restrict__ hit_tri,
-                                                                          unsigned long long* ray_counter, const float4* __restrict__ lean_origin) {
+                                                                          unsigned long long* ray_counter, const float4* __restrict__ lean_origin, CancelRef cancel) {
     __shared__ uint4 lds_stack[(YK_PKT_BLOCK / YK_WAVE) * YK_PKT_STACK];
     PktStack stk;
     stk.base = lds_stack + (threadIdx.x / YK_WAVE) * YK_PKT_STACK;
-    const unsigned n = *count_ptr;
+    const unsigned n = cancel_raised(cancel) ? 0u : *count_ptr;
     if (ray_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter, (unsigned long long)n);
     const V3 root_lo = V3{sc.root_bmin[0], sc.root_bmin[1], sc.root_bmin[2]}, root_hi = V3{sc.root_bmax[0], sc.root_bmax[1], sc.root_bmax[2]};
     // one atomic per YK_PKT_CHUNK packets: a per-packet atomic on the single head word would
@@ -203,7 +203,10 @@ __global__ __launch_bounds__(YK_PKT_BLOCK, 8) void k_trace_closest_packet(DevSce
     const unsigned per_claim = pkt_claim_size(n);
     for (;;) {
         unsigned claim = 0;
-        if (lane_id() == 0) claim = atomicAdd(head, per_claim);
+        if (lane_id() == 0) {
+            claim = atomicAdd(head, per_claim);
+            if (blockIdx.x == 0 && threadIdx.x == 0 && cancel_relay(cancel, head)) claim = 0xffffffffu;  // interrupted (yk_device.h): the head is poisoned, nobody claims again
+        }
         claim = uni(claim);
         if (claim >= n) break;
         const unsigned claim_end = claim + per_claim < n ? claim + per_claim : n;
@@ -243,17 +246,20 @@ __global__ __launch_bounds__(YK_PKT_BLOCK, 8) void k_trace_closest_packet(DevSce
 template <bool SPHERES>
 __global__ __launch_bounds__(YK_PKT_BLOCK, 8) void k_trace_any_packet(DevScene sc, const float4* __restrict__ shO, const float4* __restrict__ shD,
                                                                       const unsigned* __restrict__ slot_of, const unsigned* count_ptr, unsigned* head,
-                                                                      unsigned char* __restrict__ vis, unsigned long long* shadow_counter) {
+                                                                      unsigned char* __restrict__ vis, unsigned long long* shadow_counter, CancelRef cancel) {
     __shared__ uint4 lds_stack[(YK_PKT_BLOCK / YK_WAVE) * YK_PKT_STACK];
     PktStack stk;
     stk.base = lds_stack + (threadIdx.x / YK_WAVE) * YK_PKT_STACK;
-    const unsigned n = *count_ptr;
+    const unsigned n = cancel_raised(cancel) ? 0u : *count_ptr;
     if (shadow_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(shadow_counter, (unsigned long long)n);
     const V3 root_lo = V3{sc.root_bmin[0], sc.root_bmin[1], sc.root_bmin[2]}, root_hi = V3{sc.root_bmax[0], sc.root_bmax[1], sc.root_bmax[2]};
     const unsigned per_claim = pkt_claim_size(n);
     for (;;) {
         unsigned claim = 0;
-        if (lane_id() == 0) claim = atomicAdd(head, per_claim);
+        if (lane_id() == 0) {
+            claim = atomicAdd(head, per_claim);
+            if (blockIdx.x == 0 && threadIdx.x == 0 && cancel_relay(cancel, head)) claim = 0xffffffffu;  // interrupted (yk_device.h): the head is poisoned, nobody claims again
+        }
         claim = uni(claim);
         if (claim >= n) break;
         const unsigned claim_end = claim + per_claim < n ? claim + per_claim : n;
@@ -370,18 +376,18 @@ __global__ __launch_bounds__(YK_PKT_BLOCK, 8) void k_trace_any_packet(DevScene s
 unsigned packet_blocks_per_cu() { return 8u; }
 
 void launch_trace_closest_packet(hipStream_t s, unsigned grid, const DevScene& sc, const float4* rayO, const float4* rayD, const unsigned* count_ptr,
-                                 unsigned* head, int* hit_tri, unsigned long long* ray_counter, const float4* lean_origin) {
+                                 unsigned* head, int* hit_tri, unsigned long long* ray_counter, const float4* lean_origin, CancelRef cancel) {
     if (sc.spheres)
-        hipLaunchKernelGGL((k_trace_closest_packet<true>), dim3(grid), dim3(YK_PKT_BLOCK), 0, s, sc, rayO, rayD, count_ptr, head, hit_tri, ray_counter, lean_origin);
+        hipLaunchKernelGGL((k_trace_closest_packet<true>), dim3(grid), dim3(YK_PKT_BLOCK), 0, s, sc, rayO, rayD, count_ptr, head, hit_tri, ray_counter, lean_origin, cancel);
     else
-        hipLaunchKernelGGL((k_trace_closest_packet<false>), dim3(grid), dim3(YK_PKT_BLOCK), 0, s, sc, rayO, rayD, count_ptr, head, hit_tri, ray_counter, lean_origin);
+        hipLaunchKernelGGL((k_trace_closest_packet<false>), dim3(grid), dim3(YK_PKT_BLOCK), 0, s, sc, rayO, rayD, count_ptr, head, hit_tri, ray_counter, lean_origin, cancel);
 }
 void launch_trace_any_packet(hipStream_t s, unsigned grid, const DevScene& sc, const float4* shO, const float4* shD, const unsigned* slot_of,
-                             const unsigned* count_ptr, unsigned* head, unsigned char* vis, unsigned long long* shadow_counter) {
+                             const unsigned* count_ptr, unsigned* head, unsigned char* vis, unsigned long long* shadow_counter, CancelRef cancel) {
     if (sc.spheres)
-        hipLaunchKernelGGL((k_trace_any_packet<true>), dim3(grid), dim3(YK_PKT_BLOCK), 0, s, sc, shO, shD, slot_of, count_ptr, head, vis, shadow_counter);
+        hipLaunchKernelGGL((k_trace_any_packet<true>), dim3(grid), dim3(YK_PKT_BLOCK), 0, s, sc, shO, shD, slot_of, count_ptr, head, vis, shadow_counter, cancel);
     else
-        hipLaunchKernelGGL((k_trace_any_packet<false>), dim3(grid), dim3(YK_PKT_BLOCK), 0, s, sc, shO, shD, slot_of, count_ptr, head, vis, shadow_counter);
+        hipLaunchKernelGGL((k_trace_any_packet<false>), dim3(grid), dim3(YK_PKT_BLOCK), 0, s, sc, shO, shD, slot_of, count_ptr, head, vis, shadow_counter, cancel);
 }
 
 }  // namespace yk

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "yk_internal.h"
@@ -24,7 +25,8 @@
 // ctx->counters: 8 x u64 (closest-hit rays, shadow rays, ...) followed by a 4-word error block whose word
 // YK_CTRL_ERR the traversal kernels set on a stack overflow.  Both are zeroed ONCE per call (begin_call) — the
 // per-batch control blocks of the work sets are zeroed with every batch and must not hold the flag.
-unsigned* error_block(yk_context* ctx) { return reinterpret_cast<unsigned*>(ctx->counters.as<unsigned long long>() + 8); }
+unsigned* error_block(yk_context* ctx) { return reinterpret_cast<unsigned*>(ctx->counters.as<unsigned long long>() + 16); }
+CancelRef cancel_ref(yk_context* ctx) { return CancelRef{ctx->cancel_host_dev, ctx->cancel_host_dev ? error_block(ctx) + YK_CTRL_CANCELLED : nullptr}; }
 
 yk_status ensure_work_buffers(yk_context* ctx, WorkSet& ws, size_t paths, unsigned n_lights, unsigned n_delta_lights) {
     HIP_TRY(ctx, ctx->counters.ensure(YK_COUNTER_BYTES));
@@ -154,10 +156,10 @@ void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* s
         unsigned* bc = ctrl + YK_CTRL_BOUNCE(b);  // this bounce's counters and queue heads, zeroed with the batch
         int e = kt.begin(st);
         if (packet)
-            launch_trace_closest_packet(st, pg, ds, lean_origin ? nullptr : pc.rayO, pc.rayD, bc, bc + YK_CTRL_HEAD, ws.hit.as<int>(), counters, lean_origin);
+            launch_trace_closest_packet(st, pg, ds, lean_origin ? nullptr : pc.rayO, pc.rayD, bc, bc + YK_CTRL_HEAD, ws.hit.as<int>(), counters, lean_origin, prm.cancel);
         else
             launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, bc, bc + YK_CTRL_HEAD, ws.hit.as<int>(), nullptr, nullptr,
-                                 ws.spill.as<uint2>(), spill_stride, errblk, counters);
+                                 ws.spill.as<uint2>(), spill_stride, errblk, counters, prm.cancel.host);
         kt.end(e, 0, st);
         if (overlap && b > 0) (void)hipStreamWaitEvent(st, ws.ev_acc, 0);
         e = kt.begin(st);
@@ -173,14 +175,14 @@ void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* s
         uint2* any_spill = (overlap ? ws.spill_side : ws.spill).as<uint2>();
         if (all_delta) {
             launch_trace_any_packet(sb, pg_any, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), bc + YK_CTRL_SHQ,
-                                    bc + YK_CTRL_HEAD + 1, ws.vis.as<unsigned char>(), counters + 1);
+                                    bc + YK_CTRL_HEAD + 1, ws.vis.as<unsigned char>(), counters + 1, prm.cancel);
         } else {
             launch_trace_any(sb, tg_any, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), bc + YK_CTRL_SHQ,
-                             bc + YK_CTRL_HEAD + 1, ws.vis.as<unsigned char>(), any_spill, spill_stride, errblk, counters + 1);
+                             bc + YK_CTRL_HEAD + 1, ws.vis.as<unsigned char>(), any_spill, spill_stride, errblk, counters + 1, prm.cancel.host);
             if (split && n_shadow_launches) ++*n_shadow_launches;
             if (split)  // rays converging on a point / spot / distant light: wave packets
                 launch_trace_any_packet(sb, pg_any, ds, ws.shO2.as<float4>(), ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc + YK_CTRL_SHQ2,
-                                        bc + YK_CTRL_HEAD + 2, ws.vis.as<unsigned char>(), counters + 1);
+                                        bc + YK_CTRL_HEAD + 2, ws.vis.as<unsigned char>(), counters + 1, prm.cancel);
         }
         kt.end(e, 1, sb);
         if (n_shadow_launches) ++*n_shadow_launches;
@@ -203,13 +205,59 @@ void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* s
     if (overlap) (void)hipStreamWaitEvent(st, ws.ev_acc, 0);  // the batch is complete on `st` once its last accumulate is
 }
 
+// ------------------------------------------------------------------ interruption (yk_device.h, CancelRef)
+// Raise the host's word: the persistent kernels see it at their next claim, k_shade at its next window, and they raise the
+// device word that every later launch reads when it starts.
+static void raise_cancel(yk_context* ctx, bool from_render_thread = true) {
+    if (!ctx->cancel_host) return;
+    ctx->cancel_raised.store(true, std::memory_order_release);
+    __atomic_store_n(ctx->cancel_host, 1u, __ATOMIC_RELEASE);
+    // ... and the device word directly (a copy engine's job: it does not queue behind the kernels): k_shade looks at this one only
+    if (from_render_thread && ctx->cancel_stream && ctx->counters.p)
+        (void)hipMemcpyAsync(error_block(ctx) + YK_CTRL_CANCELLED, ctx->cancel_host + 16, 4, hipMemcpyHostToDevice, ctx->cancel_stream);
+}
+
+// Called by a submission before it enqueues anything: if an earlier one was interrupted, whatever it still has on the
+// context's streams drains first — the word may only be cleared when no kernel that honoured it can run again.
+static yk_status clear_cancel(yk_context* ctx) {
+    if (!ctx->cancel_host || !ctx->cancel_raised.load(std::memory_order_acquire)) return YK_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->cancel_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->cancel_stream));  // a late copy of the 1 must not land in the next submission
+    for (WorkSet& w : ctx->ws) {
+        if (w.stream && w.stream != ctx->stream) HIP_TRY(ctx, hipStreamSynchronize(w.stream));
+        if (w.side) HIP_TRY(ctx, hipStreamSynchronize(w.side));
+    }
+    __atomic_store_n(ctx->cancel_host, 0u, __ATOMIC_RELEASE);
+    ctx->cancel_raised.store(false, std::memory_order_release);
+    return YK_OK;
+}
+
+// Wait for `done` (recorded on the stream that ends the submission) while polling the caller's predicate about every
+// 100 us — the reference polls it once per pixel sample (integrators/mod.rs:153; render_worker.rs:240-255 relies on
+// that for "low latency kills").  Returns true when the predicate fired: the word is raised and the streams have drained.
+static bool poll_until(yk_context* ctx, hipEvent_t done, yk_cancel_fn cancel, void* user) {
+    while (hipEventQuery(done) == hipErrorNotReady) {
+        if (cancel(user)) {
+            raise_cancel(ctx);
+            return true;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    return false;
+}
+static bool wait_polling(yk_context* ctx, hipEvent_t done, hipStream_t st, yk_cancel_fn cancel, void* user) {
+    const bool fired = cancel ? poll_until(ctx, done, cancel, user) : false;
+    (void)hipStreamSynchronize(st);
+    return fired;
+}
+
 // Integrator::render for a list of tiles.  tile_samples == nullptr: the plain film (all
 // samples of a pixel, mean stored).  Otherwise the accumulating film (integrators/mod.rs:
 // 146-161): one sample per pixel with global index tile_samples[t], raw value stored.
 static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
                                    const yk_integrator_desc* integrator, const yk_tile* tiles, const uint16_t* tile_samples, size_t n_tiles,
                                    void* d_out_rgb, void* stream, yk_render_stats* stats, yk_cancel_fn cancel, void* user,
-                                   const yk_tile_list* prepared = nullptr, uint32_t n_passes = 1) try {
+                                   const yk_tile_list* prepared = nullptr, uint32_t n_passes = 1, int64_t uniform_first_sample = -1) try {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
     if (prepared) {
@@ -226,6 +274,10 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
     if (prm.integrator == YK_INTEGRATOR_PATH && prm.max_depth > YK_CTRL_MAX_DEPTH)
         return fail(ctx, YK_ERR_INVALID_ARGUMENT, "max_depth too large");
     (void)hipSetDevice(ctx->device);
+    {
+        yk_status cs = clear_cancel(ctx);
+        if (cs != YK_OK) return cs;
+    }
     // The render always runs on the context's own streams; a caller's stream hands over to them
     // and takes over again at the end (two event waits), so the work is ordered on it as if it
     // had been launched there — and the main / side stream pair keeps its own hardware queues.
@@ -253,7 +305,9 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         if (total_px > 0xFFFFFFFFull) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "too many pixels in one call");
         off[t + 1] = (uint32_t)total_px;
     }
-    const bool accumulating = tile_samples != nullptr;
+    // accumulating film: FilmTile.sample per tile (tile_samples), or one sample index shared by all tiles
+    const bool accumulating = tile_samples != nullptr || uniform_first_sample >= 0;
+    if (tile_samples && uniform_first_sample >= 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "an accumulating tile list carries its own sample indices");
     if (n_passes == 0 || n_passes > 0xFFFFu || (!accumulating && n_passes != 1)) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "bad number of passes");
     // samples rendered per pixel by this call: the accumulating film renders passes FilmTile.sample .. + n_passes - 1
     const uint32_t spp = accumulating ? n_passes : prm.sampler.spp;
@@ -261,10 +315,14 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
     if (accumulating) {
         // render_manager.rs:135-143 queues samples 0 .. spp-1 of a tile and nothing else; an index beyond that is
         // outside the samplers' domain (the stratified permutation walks cycles of [0, spp) and need not terminate)
-        for (size_t t = 0; t < n_tiles; ++t)
+        for (size_t t = 0; tile_samples && t < n_tiles; ++t)
             if ((uint64_t)tile_samples[t] + n_passes > prm.sampler.spp)
                 return fail(ctx, YK_ERR_INVALID_ARGUMENT, "FilmTile.sample (+ passes) beyond the sampler's samples per pixel");
+        if (uniform_first_sample >= 0 && (uint64_t)uniform_first_sample + n_passes > prm.sampler.spp)
+            return fail(ctx, YK_ERR_INVALID_ARGUMENT, "first_sample (+ passes) beyond the sampler's samples per pixel");
+        if (uniform_first_sample >= 0) prm.sample_base = (uint32_t)uniform_first_sample;
     }
+    const bool sample_table = tile_samples != nullptr;  // a per-pixel table of sample indices (absent: prm.sample_base for every pixel)
     // chunk so that sample ids fit u32 and the sample buffer stays under the cap
     uint64_t max_px_chunk = std::min<uint64_t>(0xFFFFFFF0ull / spp, (uint64_t)ctx->sample_buf_cap / (16ull * spp));
     if (max_px_chunk == 0) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "sample_buf_cap too small for one pixel");
@@ -305,8 +363,9 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
     if (!is_path && prm.integrator == YK_INTEGRATOR_BVH_INTERSECTIONS) HIP_TRY(ctx, ctx->stats4.ensure(batch * 16));
 
     unsigned long long* counters = ctx->counters.as<unsigned long long>();
-    HIP_TRY(ctx, hipMemsetAsync(counters, 0, YK_COUNTER_BYTES, st));
+    HIP_TRY(ctx, hipMemsetAsync(counters, 0, YK_COUNTER_BYTES, st));  // the error block with it: stack-overflow flag, interruption word
     unsigned* errblk = error_block(ctx);
+    prm.cancel = cancel_ref(ctx);
     KernelTimer kt;
     kt.ctx = ctx;
     // per-kernel HIP-event timings: two event records per launch and one elapsed-time query per
@@ -342,15 +401,15 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         const uint16_t* d_tile_sample = nullptr;
         if (prepared) {  // the pixel table of the whole list is already on the device
             pixel_xy = prepared->pixel_xy.as<uint32_t>() + px0;
-            if (accumulating) pixel_sample = prepared->pixel_sample.as<uint32_t>() + px0;
+            if (sample_table) pixel_sample = prepared->pixel_sample.as<uint32_t>() + px0;
         } else if (t_end - t_begin == 1) {  // one tile (the reference's per-tile call): it travels as a kernel argument
             HIP_TRY(ctx, ctx->pixel_xy.ensure((size_t)npx * 4));
             pixel_xy = ctx->pixel_xy.as<uint32_t>();
-            if (accumulating) {
+            if (sample_table) {
                 HIP_TRY(ctx, ctx->scratch[5].ensure((size_t)npx * 4));
                 pixel_sample = ctx->scratch[5].as<uint32_t>();
             }
-            launch_pixel_table_one(st, tiles[t_begin], npx, pixel_xy, accumulating ? tile_samples[t_begin] : 0u, pixel_sample);
+            launch_pixel_table_one(st, tiles[t_begin], npx, pixel_xy, sample_table ? tile_samples[t_begin] : 0u, pixel_sample);
         } else {
         std::vector<uint32_t> loc(t_end - t_begin + 1);
         for (size_t t = t_begin; t <= t_end; ++t) loc[t - t_begin] = off[t] - px0;
@@ -359,7 +418,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         HIP_TRY(ctx, hipStreamSynchronize(st));  // `loc` is a stack-lifetime staging buffer
         HIP_TRY(ctx, ctx->pixel_xy.ensure((size_t)npx * 4));
         pixel_xy = ctx->pixel_xy.as<uint32_t>();
-        if (accumulating) {
+        if (sample_table) {
             HIP_TRY(ctx, ctx->scratch[4].ensure((t_end - t_begin) * 2));
             HIP_TRY(ctx, ctx->scratch[5].ensure((size_t)npx * 4));
             HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[4].p, tile_samples + t_begin, (t_end - t_begin) * 2, hipMemcpyHostToDevice, st));
@@ -379,13 +438,23 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
 
         const uint64_t work = (uint64_t)npx * spp;
         int which = 0;
+        bool ws_busy[2] = {false, false};
         for (uint64_t w0 = 0; w0 < work; w0 += batch) {
-            if (cancel && cancel(user)) {
+            WorkSet& ws = ctx->ws[which];
+            // An interruptible job of many batches is not enqueued all at once: a work set takes its next batch when its
+            // previous one has finished (the other work set's batch keeps the GPU busy meanwhile), the predicate is polled
+            // during the wait, and an interruption has at most two batches' launches left to drain — each of them an empty
+            // launch of a few microseconds, but a 4K x 256 spp job holds 1300 of them.
+            bool fired = cancel && ws_busy[which] && poll_until(ctx, ws.ev_batch, cancel, user);
+            if (!fired && cancel && cancel(user)) {
+                raise_cancel(ctx);
+                fired = true;
+            }
+            if (fired) {  // what is already enqueued drains at once
                 (void)hipStreamSynchronize(st);
                 if (n_ws == 2) (void)hipStreamSynchronize(ctx->ws[1].stream);
                 return fail(ctx, YK_ERR_CANCELLED, "cancelled by early_termination_predicate");
             }
-            WorkSet& ws = ctx->ws[which];
             hipStream_t bs = n_ws == 2 ? ws.stream : st;
             unsigned* ctrl = ws.ctrl.as<unsigned>();
             const uint32_t n = (uint32_t)std::min<uint64_t>(batch, work - w0);
@@ -416,6 +485,10 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
                 launch_debug_shade(bs, scene->dev, prm.integrator, pc, ws.hit.as<int>(), ctx->stats4.as<uint4>(), n, sample_buf);
                 ++n_trace;
             }
+            if (cancel) {
+                HIP_TRY(ctx, hipEventRecord(ws.ev_batch, bs));
+                ws_busy[which] = true;
+            }
             if (n_ws == 2) which ^= 1;
         }
         if (n_ws == 2) {  // resolve (on the caller-visible stream) waits for the second stream
@@ -431,12 +504,15 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
     HIP_TRY(ctx, hipGetLastError());
     if (stats) {
         HIP_TRY(ctx, hipEventRecord(ev1, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
+        // a synchronous call: the predicate is polled while the GPU works
+        if (wait_polling(ctx, ev1, st, cancel, user)) return fail(ctx, YK_ERR_CANCELLED, "cancelled by early_termination_predicate");
+        if (ctx->cancel_raised.load(std::memory_order_acquire)) return fail(ctx, YK_ERR_CANCELLED, "interrupted (yk_context_interrupt)");
+        HIP_TRY(ctx, hipGetLastError());
         std::memset(stats, 0, sizeof(*stats));
         unsigned long long host_counters[YK_COUNTER_BYTES / 8];
         HIP_TRY(ctx, hipMemcpy(host_counters, counters, YK_COUNTER_BYTES, hipMemcpyDeviceToHost));
         unsigned host_err[4];
-        std::memcpy(host_err, host_counters + 8, sizeof(host_err));
+        std::memcpy(host_err, host_counters + 16, sizeof(host_err));
         float ms = 0.0f;
         (void)hipEventElapsedTime(&ms, ev0, ev1);
         stats->rays = host_counters[0];
@@ -582,6 +658,25 @@ yk_status yk_render_tile_list_passes_device(yk_context* ctx, const yk_scene* sce
     if (list->samples.empty()) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "passes need an accumulating tile list (tile_samples)");
     return render_tiles_impl(ctx, scene, camera, sampler, integrator, list->tiles.data(), nullptr, list->tiles.size(), d_out_rgb, stream, stats, cancel,
                              user, list, n_passes);
+}
+
+yk_status yk_render_tile_list_samples_device(yk_context* ctx, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                             const yk_integrator_desc* integrator, const yk_tile_list* list, uint32_t first_sample, uint32_t n_passes,
+                                             void* d_out_rgb, void* stream, yk_render_stats* stats, yk_cancel_fn cancel, void* user) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    if (!list) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "null tile list");
+    if (!list->samples.empty()) return fail(ctx, YK_ERR_INVALID_ARGUMENT, "the list carries per-tile sample indices: use yk_render_tile_list_passes_device");
+    return render_tiles_impl(ctx, scene, camera, sampler, integrator, list->tiles.data(), nullptr, list->tiles.size(), d_out_rgb, stream, stats, cancel,
+                             user, list, n_passes, (int64_t)first_sample);
+}
+
+// An interruption from any thread (the call that renders holds the context's lock for its whole duration, this one
+// takes none): what the context has enqueued stops at the kernels' next look at the word, the next submission waits
+// for it to drain and clears the word.
+yk_status yk_context_interrupt(yk_context* ctx) {
+    if (!ctx) return YK_ERR_INVALID_ARGUMENT;
+    raise_cancel(ctx, false);  // the host word only: no HIP call from a thread that may not have the device current
+    return YK_OK;
 }
 
 static yk_status film_update_list(yk_context* ctx, const yk_tile_list* list, const void* d_tile_rgb, uint16_t res_x, uint16_t res_y, void* d_film_rgb,

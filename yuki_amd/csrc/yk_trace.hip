@@ -339,7 +339,9 @@ struct ChunkCursor {
     // passes) is cut into equal shares instead, wave w takes share w and nothing else: the
     // two atomics per wave of the dynamic scheme (a claim and a failed claim, ~14 K per launch on
     // one address at ~100 M/s) were most of what such a launch cost beyond its longest ray.
-    template <int CHUNK> __device__ __forceinline__ unsigned take(bool want, unsigned n, unsigned* head) {
+    // `cancel`: the launch's relay wave (first wave of block 0) also looks at the host's interruption word when it claims
+    // (yk_device.h); finding it set it poisons the head, and every wave's next claim comes back beyond the queue's end.
+    template <int CHUNK> __device__ __forceinline__ unsigned take(bool want, unsigned n, unsigned* head, const CancelRef& cancel) {
         unsigned long long mask = __ballot(want);
         if (mask == 0ull || exhausted) return 0xffffffffu;
         if (cur >= end) {
@@ -358,7 +360,10 @@ struct ChunkCursor {
             } else {
                 chunk = (unsigned)CHUNK;
                 base = 0;
-                if (lane_id() == 0) base = atomicAdd(head, chunk);
+                if (lane_id() == 0) {
+                    base = atomicAdd(head, chunk);
+                    if (blockIdx.x == 0 && threadIdx.x == 0 && cancel_relay(cancel, head)) base = 0xffffffffu;
+                }
                 base = __shfl(base, 0);
             }
             if (base >= n) {
@@ -380,7 +385,7 @@ template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int
 __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(DevScene sc, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
                                                             const float* __restrict__ t_max_opt, const unsigned* count_ptr, unsigned* head,
                                                             int* __restrict__ hit_tri, float4* __restrict__ hit_out, uint2* spill,
-                                                            unsigned spill_stride, unsigned* ctrl, unsigned long long* ray_counter) {
+                                                            unsigned spill_stride, unsigned* ctrl, unsigned long long* ray_counter, const unsigned* cancel_host) {
     __shared__ unsigned long long lds_stack[LDS_DEPTH * BLOCK];
     __shared__ float4 lds_top[WIDE ? 1 : TRACE_TOP * 4];
     if (!WIDE) fill_top<BLOCK>(lds_top, sc.top_nodes, sc.n_top);
@@ -389,7 +394,8 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(Dev
     stk.spill = (glb_u64*)spill;
     stk.spill_stride = spill_stride;
     stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
-    const unsigned n = *count_ptr;
+    const CancelRef cancel = CancelRef{cancel_host, cancel_host ? ctrl + YK_CTRL_CANCELLED : nullptr};  // render loop: ctrl is the context's error block
+    const unsigned n = cancel_raised(cancel) ? 0u : *count_ptr;
     if (ray_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter, (unsigned long long)n);
     const unsigned root = WIDE ? 0u : (sc.n_top ? YK_TOP_BIT : sc.root_ref);
     const V3 root_lo = V3{sc.root_bmin[0], sc.root_bmin[1], sc.root_bmin[2]}, root_hi = V3{sc.root_bmax[0], sc.root_bmax[1], sc.root_bmax[2]};
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_closest_pt(Dev
         {
             unsigned n_need = (unsigned)__popcll(__ballot(!pf_valid));
             if (!work.exhausted && (n_need >= (unsigned)PF_MIN || !__any(active))) {
-                unsigned idx = work.take<CHUNK>(!pf_valid, n, head);
+                unsigned idx = work.take<CHUNK>(!pf_valid, n, head, cancel);
                 if (idx != 0xffffffffu) {
                     pf_o = rayO[idx];
                     pf_d = rayD[idx];
@@ -559,7 +565,7 @@ template <int BLOCK, int LDS_DEPTH, int PF_MIN, int START_MIN, int LEAF_MIN, int
 __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScene sc, const float4* __restrict__ shO, const float4* __restrict__ shD,
                                                         const unsigned* __restrict__ slot_of, const unsigned* count_ptr, unsigned* head,
                                                         unsigned char* __restrict__ vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
-                                                        unsigned long long* shadow_counter) {
+                                                        unsigned long long* shadow_counter, const unsigned* cancel_host) {
     __shared__ unsigned lds_stack[LDS_DEPTH * BLOCK];
     __shared__ float4 lds_top[WIDE ? 1 : TRACE_ANY_TOP * 4];
     if (!WIDE) fill_top<BLOCK>(lds_top, sc.top_nodes_any, sc.n_top_any);
@@ -568,7 +574,8 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScen
     stk.spill = (glb_u32*)spill;
     stk.spill_stride = spill_stride;
     stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
-    const unsigned n = *count_ptr;
+    const CancelRef cancel = CancelRef{cancel_host, cancel_host ? ctrl + YK_CTRL_CANCELLED : nullptr};
+    const unsigned n = cancel_raised(cancel) ? 0u : *count_ptr;
     if (shadow_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(shadow_counter, (unsigned long long)n);
     const unsigned root = WIDE ? 0u : (sc.n_top_any ? YK_TOP_BIT : sc.root_ref);
     const V3 root_lo = V3{sc.root_bmin[0], sc.root_bmin[1], sc.root_bmin[2]}, root_hi = V3{sc.root_bmax[0], sc.root_bmax[1], sc.root_bmax[2]};
@@ -606,7 +613,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_MIN_WAVES) void k_trace_any_pt(DevScen
         {
             unsigned n_need = (unsigned)__popcll(__ballot(!pf_valid));
             if (!work.exhausted && (n_need >= (unsigned)PF_MIN || !__any(active))) {
-                unsigned k = work.take<CHUNK>(!pf_valid, n, head);
+                unsigned k = work.take<CHUNK>(!pf_valid, n, head, cancel);
                 if (k != 0xffffffffu) {
                     pf_o = shO[k];
                     pf_d = shD[k];
@@ -852,6 +859,7 @@ __global__ __launch_bounds__(BLOCK) void k_whitted(DevScene sc, RenderParams prm
     stk.gtid = blockIdx.x * BLOCK + threadIdx.x;
     unsigned* err = ctrl + YK_CTRL_ERR;
     unsigned long long n_rays = 0, n_shadow = 0;
+    if (cancel_raised(prm.cancel)) n = 0;  // interrupted before this launch started (yk_device.h, CancelRef)
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         const float4 a = cur.rayO[i], b = cur.rayD[i], c = cur.thru[i];
         const uint4 r = cur.rngs[i];
@@ -866,7 +874,7 @@ __global__ __launch_bounds__(BLOCK) void k_whitted(DevScene sc, RenderParams prm
         const uint32_t xy = pixel_xy[pix];
         st.px = xy & 0xffffu;
         st.py = xy >> 16;
-        st.sample_index = (sample_index_tab ? sample_index_tab[pix] : 0u) + ks;
+        st.sample_index = (sample_index_tab ? sample_index_tab[pix] : prm.sample_base) + ks;
         WhittedFrame frames[YK_WHITTED_MAX_DEPTH];
         int sp = 0;  // frames on the stack = depth of the call being evaluated
         bool is_specular = false;
@@ -1002,7 +1010,7 @@ unsigned trace_blocks_per_cu() {
 
 void launch_trace_closest(hipStream_t s, unsigned grid, const DevScene& sc, const float4* rayO, const float4* rayD, const float* t_max_opt,
                           const unsigned* count_ptr, unsigned* head, int* hit_tri, float4* hit_out, uint4* stats_out, uint2* spill,
-                          unsigned spill_stride, unsigned* ctrl, unsigned long long* ray_counter) {
+                          unsigned spill_stride, unsigned* ctrl, unsigned long long* ray_counter, const unsigned* cancel_host) {
     if (stats_out)
         hipLaunchKernelGGL((k_trace_closest<TRACE_BLOCK, TRACE_LDS, true>), dim3(grid), dim3(TRACE_BLOCK), 0, s, sc, rayO, rayD, t_max_opt, count_ptr,
                            head, hit_tri, hit_out, stats_out, spill, spill_stride, ctrl, ray_counter);
@@ -1010,7 +1018,7 @@ void launch_trace_closest(hipStream_t s, unsigned grid, const DevScene& sc, cons
         const bool api = t_max_opt != nullptr || hit_out != nullptr;
 #define YK_LAUNCH_CLOSEST(SPH, API, WIDE)                                                                                                              \
     hipLaunchKernelGGL((k_trace_closest_pt<TRACE_BLOCK, TRACE_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, SPH, API, WIDE>), dim3(grid), \
-                       dim3(TRACE_BLOCK), 0, s, sc, rayO, rayD, t_max_opt, count_ptr, head, hit_tri, hit_out, spill, spill_stride, ctrl, ray_counter)
+                       dim3(TRACE_BLOCK), 0, s, sc, rayO, rayD, t_max_opt, count_ptr, head, hit_tri, hit_out, spill, spill_stride, ctrl, ray_counter, cancel_host)
 #define YK_LAUNCH_CLOSEST_W(SPH, API) \
     if (sc.nodes4) YK_LAUNCH_CLOSEST(SPH, API, true); else YK_LAUNCH_CLOSEST(SPH, API, false)
         if (sc.spheres) {
@@ -1030,10 +1038,10 @@ void launch_whitted(hipStream_t s, unsigned grid, const DevScene& sc, const Rend
 unsigned whitted_max_depth() { return YK_WHITTED_MAX_DEPTH; }
 void launch_trace_any(hipStream_t s, unsigned grid, const DevScene& sc, const float4* shO, const float4* shD, const unsigned* slot_of,
                       const unsigned* count_ptr, unsigned* head, unsigned char* vis, uint2* spill, unsigned spill_stride, unsigned* ctrl,
-                      unsigned long long* shadow_counter) {
+                      unsigned long long* shadow_counter, const unsigned* cancel_host) {
 #define YK_LAUNCH_ANY(SPH, WIDE)                                                                                                                       \
     hipLaunchKernelGGL((k_trace_any_pt<TRACE_BLOCK, TRACE_ANY_LDS, TRACE_PF_MIN, TRACE_START_MIN, TRACE_LEAF_MIN, TRACE_CHUNK, SPH, WIDE>), dim3(grid),     \
-                       dim3(TRACE_BLOCK), 0, s, sc, shO, shD, slot_of, count_ptr, head, vis, spill, spill_stride, ctrl, shadow_counter)
+                       dim3(TRACE_BLOCK), 0, s, sc, shO, shD, slot_of, count_ptr, head, vis, spill, spill_stride, ctrl, shadow_counter, cancel_host)
     if (sc.spheres) {
         if (sc.nodes4) YK_LAUNCH_ANY(true, true); else YK_LAUNCH_ANY(true, false);
     } else {
