@@ -210,6 +210,8 @@ pub enum yk_context {}
 pub enum yk_scene {}
 pub enum yk_loaded_scene {}
 pub enum yk_tile_list {}
+pub const YK_MULTI_SHARED_DEVICES: u32 = 1;
+pub const YK_MULTI_PEER_COPY: u32 = 2;
 pub enum yk_multi {}
 pub enum yk_multi_scene {}
 pub enum yk_multi_film {}
@@ -245,6 +247,8 @@ extern "C" {
     pub fn yk_render_tile_list_device(ctx: *mut yk_context, scene: *const yk_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, list: *const yk_tile_list, d_out_rgb: *mut c_void, stream: *mut c_void, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
     pub fn yk_film_update_tile_list_device(ctx: *mut yk_context, list: *const yk_tile_list, d_tile_rgb: *const c_void, res_x: u16, res_y: u16, d_film_rgb: *mut c_void, stream: *mut c_void, accumulate: c_int) -> yk_status;
     pub fn yk_render_tiles_accumulating_passes(ctx: *mut yk_context, scene: *const yk_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, tiles: *const yk_tile, tile_samples: *const u16, n_tiles: usize, n_passes: u32, out_rgb: *mut f32, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
+    pub fn yk_render_tile_list_samples_device(ctx: *mut yk_context, scene: *const yk_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, list: *const yk_tile_list, first_sample: u32, n_passes: u32, d_out_rgb: *mut c_void, stream: *mut c_void, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
+    pub fn yk_context_interrupt(ctx: *mut yk_context) -> yk_status;
     pub fn yk_render_tile_list_passes_device(ctx: *mut yk_context, scene: *const yk_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, list: *const yk_tile_list, n_passes: u32, d_out_rgb: *mut c_void, stream: *mut c_void, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
     pub fn yk_film_accumulate_tile_list_passes_device(ctx: *mut yk_context, list: *const yk_tile_list, d_passes_rgb: *const c_void, n_passes: u32, res_x: u16, res_y: u16, d_film_rgb: *mut c_void, stream: *mut c_void) -> yk_status;
     pub fn yk_write_exr(path: *const c_char, width: u32, height: u32, rgb: *const f32) -> yk_status;
@@ -261,6 +265,8 @@ extern "C" {
     pub fn yk_loader_last_error() -> *const c_char;
     // several GPUs of one process (RenderManager's role for GPU workers) and one process per GPU
     pub fn yk_multi_create(devices: *const c_int, n_devices: u32, out: *mut *mut yk_multi) -> yk_status;
+    pub fn yk_multi_create_ex(devices: *const c_int, n_devices: u32, flags: u32, out: *mut *mut yk_multi) -> yk_status;
+    pub fn yk_multi_deal(res_x: u16, res_y: u16, tile_dim: u16, n_ranks: u32, rank: u32, out: *mut yk_tile, cap: usize, out_pixels: *mut u64) -> usize;
     pub fn yk_multi_destroy(m: *mut yk_multi);
     pub fn yk_multi_device_count(m: *const yk_multi) -> u32;
     pub fn yk_multi_context(m: *mut yk_multi, rank: u32) -> *mut yk_context;
@@ -273,6 +279,8 @@ extern "C" {
     pub fn yk_multi_film_destroy(film: *mut yk_multi_film);
     pub fn yk_multi_film_device_ptr(film: *const yk_multi_film) -> *mut c_void;
     pub fn yk_multi_render_film(m: *mut yk_multi, scene: *const yk_multi_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, film: *mut yk_multi_film, film_rgb: *mut f32, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
+    pub fn yk_multi_accumulate_film(m: *mut yk_multi, scene: *const yk_multi_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, film: *mut yk_multi_film, first_sample: u32, n_passes: u32, film_rgb: *mut f32, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
+    pub fn yk_multi_film_clear(m: *mut yk_multi, film: *mut yk_multi_film) -> yk_status;
     pub fn yk_multi_sync(m: *mut yk_multi) -> yk_status;
     pub fn yk_dist_unique_id(id: *mut u8) -> yk_status;
     pub fn yk_dist_create(ctx: *mut yk_context, id: *const u8, rank: u32, world: u32, out: *mut *mut yk_dist) -> yk_status;

@@ -83,6 +83,10 @@ impl HipNode {
     }
 }
 
+/// The library calls the predicate from ONE thread at a time and never again after it returned
+/// non-zero (include/yuki_hip.h, yk_multi_render_film: the devices' host threads share a latch) —
+/// what `Receiver::try_recv` (!Sync, consuming: render_worker.rs:240-249) needs — and the first
+/// non-zero answer stops every device, so an interrupt does not cost the other GPUs' shares.
 struct CancelCtx<'a> {
     from_parent: &'a Receiver<Option<Payload>>,
     interrupted_by: Option<Option<Payload>>,
@@ -99,7 +103,12 @@ unsafe extern "C" fn cancel_trampoline(user: *mut c_void) -> c_int {
 
 /// One payload = one frame: every tile of the film on its device, then the film itself.
 /// (The per-tile queue of render_manager.rs:125-143 is not consulted: the library's deal is the
-/// same interleave over the same spiral, film.rs:333-376.)
+/// same interleave over the same spiral, film.rs:333-376.)  `payload.accumulate` (the interactive
+/// mode: render_manager.rs:125-143 re-queues every tile once per sample index and
+/// Film::update_tile adds, film.rs:260-272): all `spp` passes in submissions of PASSES passes,
+/// the film cleared first, the host's copy refreshed after each submission like the reference's
+/// per-pass tile updates.  The predicate is polled about every 100 us while the GPUs work and a
+/// non-zero answer returns within a few milliseconds (yk_cancel_fn).
 pub fn render_payload(node: &HipNode, info: WorkerInfo, payload: &Payload, from_parent: &Receiver<Option<Payload>>, to_parent: &Sender<Message>) -> Option<Option<Payload>> {
     let params = match &payload.integrator_type {
         IntegratorType::HipPath(p) => p.clone(),
@@ -111,16 +120,40 @@ pub fn render_payload(node: &HipNode, info: WorkerInfo, payload: &Payload, from_
     let mut stats = sys::yk_render_stats::default();
     let mut cancel = CancelCtx { from_parent, interrupted_by: None };
     let start = Instant::now();
-    let st = unsafe {
-        sys::yk_multi_render_film(node.multi, node.scene, &cam, &smp, &integ, node.film, pixels.as_mut_ptr() as *mut f32, &mut stats, Some(cancel_trampoline), &mut cancel as *mut CancelCtx as *mut c_void)
-    };
-    if st == sys::YK_ERR_CANCELLED {
-        return cancel.interrupted_by;
+    let user = &mut cancel as *mut CancelCtx as *mut c_void;
+    let mut rays = 0usize;
+    if payload.accumulate {
+        const PASSES: u32 = 4; // passes per submission: 1.5x the rays per second of pass-by-pass
+        let spp = payload.sampler.samples_per_pixel() as u32;
+        assert_eq!(unsafe { sys::yk_multi_film_clear(node.multi, node.film) }, sys::YK_OK);
+        let mut first = 0u32;
+        while first < spp {
+            let n = PASSES.min(spp - first);
+            let st = unsafe {
+                sys::yk_multi_accumulate_film(node.multi, node.scene, &cam, &smp, &integ, node.film, first, n, pixels.as_mut_ptr() as *mut f32, &mut stats, Some(cancel_trampoline), user)
+            };
+            if st == sys::YK_ERR_CANCELLED {
+                return cancel.interrupted_by;
+            }
+            assert_eq!(st, sys::YK_OK, "multi-GPU render failed: {}", why(node.multi));
+            first += n;
+            rays += stats.rays as usize;
+            // the running sum over `first` samples: what the film holds in accumulate mode (film.rs:260-272)
+            payload.film.lock().unwrap().set_accumulated_pixels(&pixels, first as u16);
+        }
+    } else {
+        let st = unsafe {
+            sys::yk_multi_render_film(node.multi, node.scene, &cam, &smp, &integ, node.film, pixels.as_mut_ptr() as *mut f32, &mut stats, Some(cancel_trampoline), user)
+        };
+        if st == sys::YK_ERR_CANCELLED {
+            return cancel.interrupted_by;
+        }
+        assert_eq!(st, sys::YK_OK, "multi-GPU render failed: {}", why(node.multi));
+        rays = stats.rays as usize;
+        // row-major RGB, row 0 = top: the layout of Film::pixels (film.rs:67-113)
+        payload.film.lock().unwrap().set_pixels(&pixels);
     }
-    assert_eq!(st, sys::YK_OK, "multi-GPU render failed: {}", why(node.multi));
-    // row-major RGB, row 0 = top: the layout of Film::pixels (film.rs:67-113)
-    payload.film.lock().unwrap().set_pixels(&pixels);
-    let _ = to_parent.send(Message::TileDone { info, ray_count: stats.rays as usize, elapsed_s: start.elapsed().as_secs_f32() });
+    let _ = to_parent.send(Message::TileDone { info, ray_count: rays, elapsed_s: start.elapsed().as_secs_f32() });
     let _ = to_parent.send(Message::Finished(info));
     None
 }
