@@ -20,6 +20,9 @@
 #include <vector>
 
 #include "yk_internal.h"
+#ifdef YK_EXPERIMENT_SORT  // timing builds only (tools/build_variant.sh sort -DYK_EXPERIMENT_SORT): DESIGN.md §9
+#include "../../tools/micro/ray_sort_experiment.h"
+#endif
 
 // ------------------------------------------------------------------ render
 // ctx->counters: 8 x u64 (closest-hit rays, shadow rays, ...) followed by a 4-word error block whose word
@@ -157,9 +160,14 @@ void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* s
         int e = kt.begin(st);
         if (packet)
             launch_trace_closest_packet(st, pg, ds, lean_origin ? nullptr : pc.rayO, pc.rayD, bc, bc + YK_CTRL_HEAD, ws.hit.as<int>(), counters, lean_origin, prm.cancel);
-        else
-            launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, bc, bc + YK_CTRL_HEAD, ws.hit.as<int>(), nullptr, nullptr,
+        else {
+            unsigned* head = bc + YK_CTRL_HEAD;
+#ifdef YK_EXPERIMENT_XCD
+            head = yk_exp::sorter().heads(st, 0);
+#endif
+            launch_trace_closest(st, tg, ds, pc.rayO, pc.rayD, nullptr, bc, head, ws.hit.as<int>(), nullptr, nullptr,
                                  ws.spill.as<uint2>(), spill_stride, errblk, counters, prm.cancel.host);
+        }
         kt.end(e, 0, st);
         if (overlap && b > 0) (void)hipStreamWaitEvent(st, ws.ev_acc, 0);
         e = kt.begin(st);
@@ -167,6 +175,47 @@ void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* s
                      ws.shD.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ws.shq.as<unsigned>(), ws.shO2.as<float4>(),
                      ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc, split ? 1u : 0u, (b > 0 && ctx->shade_reorder) ? 1u : 0u, 3u * (unsigned)ctx->n_cu, sid_base, lean_origin);
         kt.end(e, 2, st);
+#ifdef YK_EXPERIMENT_SORT
+        if (yk_exp::sorter().bounces > 0) {  // order the queues k_shade just wrote (synchronises: timing experiment)
+            yk_exp::Sorter& S = yk_exp::sorter();
+            unsigned h[YK_CTRL_STRIDE + 1];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h, bc, sizeof(h), hipMemcpyDeviceToHost);
+            const unsigned n_next = h[YK_CTRL_STRIDE], n_sh = h[YK_CTRL_SHQ];
+            float ms_paths = 0.0f, ms_sh = 0.0f;
+            if ((int)(b + 1) <= S.bounces && b + 1 < prm.max_depth && n_next > 1) {
+                for (int k = 0; k < 4; ++k) (void)S.spare[k].ensure(ws.path[cur ^ 1u][k].bytes);
+                (void)hipEventRecord(S.e0, st);
+                const unsigned* order = S.sort(st, pn.rayO, pn.rayD, n_next, ds);
+                PathBuffers sp;
+                sp.rayO = S.spare[0].as<float4>();
+                sp.rayD = S.spare[1].as<float4>();
+                sp.thru = S.spare[2].as<float4>();
+                sp.rngs = S.spare[3].as<uint4>();
+                hipLaunchKernelGGL(yk_exp::k_permute_paths, dim3((n_next + 255) / 256), dim3(256), 0, st, order, n_next, pn, sp);
+                (void)hipEventRecord(S.e1, st);
+                (void)hipStreamSynchronize(st);
+                (void)hipEventElapsedTime(&ms_paths, S.e0, S.e1);
+                for (int k = 0; k < 4; ++k) std::swap(ws.path[cur ^ 1u][k], S.spare[k]);
+            }
+            if (S.shadow && (int)b < S.bounces && n_sh > 1) {
+                (void)S.shO.ensure(ws.shO.bytes);
+                (void)S.shD.ensure(ws.shD.bytes);
+                (void)S.shq.ensure(ws.shq.bytes);
+                (void)hipEventRecord(S.e0, st);
+                const unsigned* order = S.sort(st, ws.shO.as<float4>(), ws.shD.as<float4>(), n_sh, ds);
+                hipLaunchKernelGGL(yk_exp::k_permute_shadow, dim3((n_sh + 255) / 256), dim3(256), 0, st, order, n_sh, ws.shO.as<float4>(), ws.shD.as<float4>(),
+                                   ws.shq.as<unsigned>(), S.shO.as<float4>(), S.shD.as<float4>(), S.shq.as<unsigned>());
+                (void)hipEventRecord(S.e1, st);
+                (void)hipStreamSynchronize(st);
+                (void)hipEventElapsedTime(&ms_sh, S.e0, S.e1);
+                std::swap(ws.shO, S.shO);
+                std::swap(ws.shD, S.shD);
+                std::swap(ws.shq, S.shq);
+            }
+            std::fprintf(stderr, "  sort after shade %u: next queue %u rays %.3f ms | area-light shadow queue %u rays %.3f ms\n", b, n_next, ms_paths, n_sh, ms_sh);
+        }
+#endif
         if (overlap) {
             (void)hipEventRecord(ws.ev_shade, st);
             (void)hipStreamWaitEvent(sb, ws.ev_shade, 0);
@@ -177,8 +226,12 @@ void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* s
             launch_trace_any_packet(sb, pg_any, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), bc + YK_CTRL_SHQ,
                                     bc + YK_CTRL_HEAD + 1, ws.vis.as<unsigned char>(), counters + 1, prm.cancel);
         } else {
+            unsigned* any_head = bc + YK_CTRL_HEAD + 1;
+#ifdef YK_EXPERIMENT_XCD
+            any_head = yk_exp::sorter().heads(sb, 1);
+#endif
             launch_trace_any(sb, tg_any, ds, ws.shO.as<float4>(), ws.shD.as<float4>(), ws.shq.as<unsigned>(), bc + YK_CTRL_SHQ,
-                             bc + YK_CTRL_HEAD + 1, ws.vis.as<unsigned char>(), any_spill, spill_stride, errblk, counters + 1, prm.cancel.host);
+                             any_head, ws.vis.as<unsigned char>(), any_spill, spill_stride, errblk, counters + 1, prm.cancel.host);
             if (split && n_shadow_launches) ++*n_shadow_launches;
             if (split)  // rays converging on a point / spot / distant light: wave packets
                 launch_trace_any_packet(sb, pg_any, ds, ws.shO2.as<float4>(), ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc + YK_CTRL_SHQ2,

@@ -328,9 +328,15 @@ template <int BLOCK, int LDS_DEPTH> __device__ __forceinline__ bool pop_closest(
 struct ChunkCursor {
     unsigned cur, end;  // wave-uniform
     bool exhausted, took_share;
+#ifdef YK_EXPERIMENT_XCD
+    unsigned xcd_step;  // ranges this wave has found drained
+#endif
     __device__ __forceinline__ void init() {
         cur = end = 0;
         exhausted = took_share = false;
+#ifdef YK_EXPERIMENT_XCD
+        xcd_step = 0;
+#endif
     }
     // hands `want` lanes consecutive indices; returns the index of this lane or
     // 0xffffffff.  All lanes of the wave call it (converged).
@@ -360,6 +366,28 @@ struct ChunkCursor {
             } else {
                 chunk = (unsigned)CHUNK;
                 base = 0;
+#ifdef YK_EXPERIMENT_XCD  // timing builds only: the queue cut into eight ranges, one per group of blocks that share an
+                          // XCD (blockIdx % 8, MI355X_MICROARCH.md); a wave claims from its own range (one atomic per claim, as before)
+                          // and moves on to the next range when that one is drained.  `head` points at eight words.
+                for (;;) {
+                    if (xcd_step >= 8u) {
+                        exhausted = true;
+                        return 0xffffffffu;
+                    }
+                    const unsigned y = ((blockIdx.x & 7u) + xcd_step) & 7u;
+                    const unsigned lo = (unsigned)((unsigned long long)n * y / 8ull), hi = (unsigned)((unsigned long long)n * (y + 1u) / 8ull);
+                    unsigned got = 0;
+                    if (lane_id() == 0) got = atomicAdd(head + y, chunk);
+                    got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+                    if (got < hi - lo) {
+                        cur = lo + got;
+                        end = cur + chunk < hi ? cur + chunk : hi;
+                        break;
+                    }
+                    ++xcd_step;
+                }
+                goto claimed;
+#endif
                 if (lane_id() == 0) {
                     base = atomicAdd(head, chunk);
                     if (blockIdx.x == 0 && threadIdx.x == 0 && cancel_relay(cancel, head)) base = 0xffffffffu;
@@ -372,6 +400,9 @@ struct ChunkCursor {
             }
             cur = base;
             end = base + chunk < n ? base + chunk : n;
+#ifdef YK_EXPERIMENT_XCD
+        claimed:;
+#endif
         }
         unsigned rank = (unsigned)__popcll(mask & ((1ull << lane_id()) - 1ull));
         unsigned idx = cur + rank;
