@@ -154,6 +154,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--scene-file", default=None,
+                    help="render a scene FILE instead of the generated one: .ply (Scene::ply, scene/mod.rs:99-152) or .pbrt (scene::pbrt::load, "
+                         "scene/pbrt/mod.rs:94-857) through yk_load_ply / yk_load_pbrt; camera from the file, film resolution from a .pbrt's Film "
+                         "directive (a .ply keeps the workload's), sampler / depth / integrator from --workload.  "
+                         "tools/write_scene_files.py writes BASELINE's configs as such files")
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--async-steps", action="store_true", help="(default since round 2 for frames of one batch) enqueue the timed steps without host synchronisation")
@@ -229,7 +234,16 @@ def main():
 
     wl = workload(args.workload)
     t0 = time.time()
-    sd = scenes.by_name(wl["scene"])
+    if args.scene_file:
+        from yuki_amd import loaders
+
+        is_pbrt = args.scene_file.lower().endswith(".pbrt")
+        sd, _cam_params, film_settings = (loaders.load_pbrt if is_pbrt else loaders.load_ply)(args.scene_file)
+        if is_pbrt:
+            wl["res"] = tuple(film_settings.res)
+        wl["desc"] = f"scene file {os.path.basename(args.scene_file)} ({sd.n_triangles} triangles, loaded by yk_load_{'pbrt' if is_pbrt else 'ply'}); sampler / depth of {args.workload}: " + wl["desc"]
+    else:
+        sd = scenes.by_name(wl["scene"])
     gen_s = time.time() - t0
     opts = {}
     if args.batch_paths:
@@ -247,7 +261,7 @@ def main():
     tiles = yk.film_tiles(fs)
     spp = yk.samples_per_pixel(sampler)
     if rank == 0:
-        log(f"[bench] scene {sd.name}: gen {gen_s:.2f}s, BVH build {info.build_seconds:.2f}s ({info.n_nodes} nodes, depth {info.tree_depth}), "
+        log(f"[bench] scene {sd.name}: {'load' if args.scene_file else 'gen'} {gen_s:.2f}s, BVH build {info.build_seconds:.2f}s ({info.n_nodes} nodes, depth {info.tree_depth}), "
             f"upload {info.upload_seconds:.2f}s, {info.device_bytes / 1e6:.0f} MB in HBM; {len(tiles)} tiles, {spp} spp")
 
     # tile i -> rank i mod G (interleaved deal of the spiral order)
@@ -560,6 +574,7 @@ def main():
                       "shadow_Mray_per_s": shadow_all / elapsed * 1e-6, "rank0_device_s_per_step": t_dev / args.steps,
                       "rank0_trace_s": t_trace / args.steps, "rank0_shadow_s": t_shadow / args.steps, "rank0_shade_s": t_shade / args.steps,
                       "two_in_flight": two_in_flight, "film_mean_rgb": film_mean, "bvh_build_s": info.build_seconds, "scene_upload_s": info.upload_seconds,
+                      "scene_load_s": gen_s if args.scene_file else None,
                       "steps_mode": "asynchronous (no host sync inside the timed region; per-kernel times and ray counts from one untimed probe step)" if async_steps
                       else "synchronous (per-kernel HIP-event times read after every step of the timed region)"},
         }

@@ -557,3 +557,102 @@ def write_exr(path, img, compression=0, half=False, extra_channels=(), data_orig
         off += len(c)
     with open(path, "wb") as f:
         f.write(hd + table + b"".join(chunks))
+
+
+# ----------------------------------------------------------------------------- BASELINE-sized scenes as files
+def write_mesh_ply(path, points, faces, normals=None, uvs=None):
+    """Binary little-endian PLY of one triangle mesh: float32 x y z [nx ny nz] [u v], faces as `list uchar uint`.
+    The arrays are written as they are (float32 bits preserved)."""
+    import numpy as np
+
+    points = np.ascontiguousarray(points, dtype=np.float32)
+    faces = np.ascontiguousarray(faces, dtype=np.uint32)
+    cols = [points]
+    h = "ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n" % len(points)
+    if normals is not None:
+        h += "property float nx\nproperty float ny\nproperty float nz\n"
+        cols.append(np.ascontiguousarray(normals, dtype=np.float32))
+    if uvs is not None:
+        h += "property float u\nproperty float v\n"
+        cols.append(np.ascontiguousarray(uvs, dtype=np.float32))
+    h += "element face %d\nproperty list uchar uint vertex_indices\nend_header\n" % len(faces)
+    rec = np.dtype([("n", "u1"), ("i", "<u4", (3,))])
+    fr = np.zeros(len(faces), dtype=rec)
+    fr["n"] = 3
+    fr["i"] = faces
+    with open(path, "wb") as f:
+        f.write(h.encode())
+        f.write(np.concatenate(cols, axis=1).astype("<f4").tobytes())
+        f.write(fr.tobytes())
+
+
+def write_cfg2_ply(path):
+    """BASELINE configs[1]'s mesh ("Stanford-bunny PLY (~70 k tri)": here the bunny-class 69,312-triangle mesh) as the file
+    Scene::ply reads: the vertices BEFORE the loader's fit-to-unit-cube transform (scene/ply.rs:99-108), so that loading the
+    file reproduces scenes.bunny_class() bit for bit."""
+    from yuki_amd import scenes
+
+    raw, tris = scenes.bunny_class_raw()
+    write_mesh_ply(path, raw, tris)
+    return path
+
+
+def _g(x):
+    return "%.9g" % float(x)  # nine significant digits: a float32 survives the text round trip exactly
+
+
+def write_scene_as_pbrt(dirname, sd, res=(1920, 1080), name="scene.pbrt"):
+    """A generated SceneData (scenes.city: BASELINE configs[2..4]) as a pbrt-v3 file plus one binary PLY per mesh — what
+    scene::pbrt::load reads (scene/pbrt/mod.rs:94-857): LookAt / Camera / Film, `LightSource "point"` and "infinite"
+    (the loader has no area lights: AreaLightSource is parsed and ignored, a rectangular light cannot be written — its
+    quad stays as geometry), one Attribute block with a Material and a `Shape "plymesh"` per mesh under the identity
+    CTM, so the loaded vertex, normal, uv and index arrays are the generator's, bit for bit and in the same order.
+    Returns (path, per-file statistics)."""
+    import numpy as np
+    from yuki_amd import abi
+
+    os.makedirs(os.path.join(dirname, "meshes"), exist_ok=True)
+    cam = sd.camera
+    out = []
+    out.append("LookAt %s  %s  %s" % (" ".join(_g(v) for v in cam["position"]), " ".join(_g(v) for v in cam["target"]), " ".join(_g(v) for v in cam["up"])))
+    out.append('Camera "perspective" "float fov" %s' % _g(cam["fov_degrees"]))
+    out.append('Film "image" "integer xresolution" [%d] "integer yresolution" [%d]' % res)
+    out.append("WorldBegin")
+    out.append('LightSource "infinite" "rgb L" [%s]' % " ".join(_g(v) for v in sd.background))
+    n_lights = 1
+    for l in sd.lights:
+        if l["kind"] == "point":
+            p = np.asarray(l["l2w"], dtype=np.float32)[:3, 3]
+            out.append('LightSource "point" "rgb I" [%s] "point from" [%s]' % (" ".join(_g(v) for v in l["I"]), " ".join(_g(v) for v in p)))
+            n_lights += 1
+    tri_mesh = np.asarray(sd.tri_mesh)
+    order = np.argsort(tri_mesh, kind="stable")
+    bounds = np.searchsorted(tri_mesh[order], np.arange(len(sd.meshes) + 1))
+    n_files = 0
+    for m, (has_n, has_uv, _swaps) in enumerate(sd.meshes):
+        tri_ids = order[bounds[m] : bounds[m + 1]]
+        if len(tri_ids) == 0:
+            continue
+        tris = sd.indices[tri_ids].astype(np.int64)
+        lo, hi = int(tris.min()), int(tris.max()) + 1
+        mat = sd.materials[int(sd.tri_material[tri_ids[0]])]
+        assert np.all(sd.tri_material[tri_ids] == sd.tri_material[tri_ids[0]]), "one material per mesh"
+        if mat["kind"] == abi.MAT_MATTE:
+            sigma = float(np.rad2deg(np.rad2deg(mat.get("c", 0.0))))  # the loader applies to_radians twice (pbrt/mod.rs:906-910)
+            md = '"matte" "rgb Kd" [%s] "float sigma" %s' % (" ".join(_g(v) for v in mat["a"]), _g(sigma))
+        elif mat["kind"] == abi.MAT_GLASS:
+            md = '"glass" "rgb Kr" [%s] "rgb Kt" [%s] "float eta" %s' % (" ".join(_g(v) for v in mat["a"]), " ".join(_g(v) for v in mat["b"]), _g(mat["c"]))
+        elif mat["kind"] == abi.MAT_METAL:
+            md = '"metal" "rgb eta" [%s] "rgb k" [%s] "float roughness" %s "bool remaproughness" "%s"' % (
+                " ".join(_g(v) for v in mat["a"]), " ".join(_g(v) for v in mat["b"]), _g(mat["c"]), "true" if mat.get("remap", True) else "false")
+        else:
+            md = '"glossy" "rgb Rs" [%s] "float roughness" %s' % (" ".join(_g(v) for v in mat["a"]), _g(mat["c"]))
+        fn = "meshes/m%05d.ply" % m
+        write_mesh_ply(os.path.join(dirname, fn), sd.points[lo:hi], tris - lo, sd.normals[lo:hi] if has_n else None, sd.uvs[lo:hi] if has_uv else None)
+        n_files += 1
+        out.append("AttributeBegin\n  Material %s\n  Shape \"plymesh\" \"string filename\" \"%s\"\nAttributeEnd" % (md, fn))
+    out.append("WorldEnd")
+    p = os.path.join(dirname, name)
+    with open(p, "w") as f:
+        f.write("\n".join(out) + "\n")
+    return p, dict(ply_files=n_files, lights=n_lights)

@@ -280,6 +280,83 @@ def test_render_scene_file_loads_identically(tmp_path, ol):
     assert got.n_triangles == 2 + 2 * 2 * 24 * 12 and len(got.spheres) == 2 and film.res == (80, 60)
 
 
+# ----------------------------------------------------------------------------- BASELINE-sized scenes through the loaders
+# BASELINE.json configs[1] is "Stanford-bunny PLY (~70 k tri)", configs[2..4] "~1 M-tri pbrt-v3 scene": the same meshes the
+# generators build (yuki_amd/scenes.py) written as the files the reference's loaders read (tests/scene_files.py) must come
+# back as the generators' arrays, bit for bit — and equal the independent loader in oracle/loaders.py.
+@pytest.fixture(scope="session")
+def cfg2_ply(tmp_path_factory):
+    return sf.write_cfg2_ply(str(tmp_path_factory.mktemp("cfg2") / "bunny_class.ply"))
+
+
+@pytest.fixture(scope="session")
+def cfg3_pbrt(tmp_path_factory, cfg3_scene):
+    p, info = sf.write_scene_as_pbrt(str(tmp_path_factory.mktemp("cfg3")), cfg3_scene)
+    assert info["ply_files"] == 802  # 800 displaced icospheres + the open box + the light's quad
+    return p
+
+
+@pytest.fixture(scope="session")
+def cfg3_oracle_loaded(cfg3_pbrt, oracle):
+    """oracle/loaders.py on the 1,024,012-triangle file set: per-vertex Python through the oracle's KAT-pinned transforms (~25 s)."""
+    from oracle import loaders as o
+
+    return o.load_pbrt(cfg3_pbrt)
+
+
+def test_cfg2_ply_file_loads_to_the_generators_arrays(cfg2_ply, ol):
+    from yuki_amd import scenes
+
+    sd = scenes.by_name("cfg2")
+    got, cam, film = loaders.load_ply(cfg2_ply)
+    assert got.n_triangles == 69312
+    # Scene::ply: fit to the unit cube (scene/ply.rs:99-108), white matte, one point light, camera at (2, 2, 2), 640 x 480
+    assert _eq(got.points, sd.points) and _eq(got.indices, sd.indices)
+    assert _eq(got.tri_material, sd.tri_material) and _eq(got.tri_area_light, sd.tri_area_light)
+    assert got.materials[0]["kind"] == abi.MAT_MATTE and _f3(got.materials[0]["a"]) == _f3((1, 1, 1))
+    assert tuple(cam.position) == (2.0, 2.0, 2.0) and film.res == (640, 480)
+    want, wcam, wres = ol.load_ply(cfg2_ply)
+    assert_same_scene(want, got)
+    assert_same_camera(wcam, cam, film, wres)
+
+
+def test_cfg3_pbrt_file_loads_to_the_generators_arrays(cfg3_pbrt, cfg3_scene, cfg3_oracle_loaded):
+    import time
+
+    sd = cfg3_scene
+    t0 = time.time()
+    got, cam, film = loaders.load_pbrt(cfg3_pbrt)
+    dt = time.time() - t0
+    print(f"yk_load_pbrt: 1,024,012 triangles from 802 PLY files + the pbrt file in {dt:.2f} s")
+    assert got.n_triangles == 1024012 and film.res == (1920, 1080)
+    assert _eq(got.points, sd.points) and _eq(got.indices, sd.indices) and _eq(got.tri_mesh, sd.tri_mesh)
+    has_n = np.array([m[0] for m in sd.meshes])[sd.tri_mesh]  # per triangle: does its mesh carry shading normals
+    v_n = np.zeros(len(sd.points), dtype=bool)
+    v_n[sd.indices[has_n].ravel()] = True
+    assert _eq(got.normals[v_n], sd.normals[v_n])
+    has_uv = np.array([m[1] for m in sd.meshes])[sd.tri_mesh]
+    v_uv = np.zeros(len(sd.points), dtype=bool)
+    v_uv[sd.indices[has_uv].ravel()] = True
+    assert v_uv.sum() == 8 and _eq(got.uvs[v_uv], sd.uvs[v_uv])
+    assert [(m[0], m[1]) for m in got.meshes] == [(m[0], m[1]) for m in sd.meshes]
+    # materials: one per mesh, constants as written (text round trip of nine digits is exact for float32); Oren-Nayar's sigma
+    # goes through the loader's two to_radians (pbrt/mod.rs:906-910) and comes back within an ulp or two of the generator's
+    assert len(got.materials) == len(sd.meshes) + 1  # the graphics state's default matte first (pbrt/mod.rs:119-131), then one per Material directive
+    assert len(got.light_structs) == 2 and _f3(got.background) == _f3(sd.background)  # two point lights; "infinite" is the background
+    for k in (0, 1, 7, 123, 799, 800):
+        a, b = got.materials[int(got.tri_material[np.searchsorted(sd.tri_mesh, k)])], sd.materials[int(sd.tri_material[np.searchsorted(sd.tri_mesh, k)])]
+        assert a["kind"] == b["kind"] and _f3(a["a"]) == _f3(b["a"])
+        assert abs(np.float32(a["c"]) - np.float32(b["c"])) <= 4 * np.spacing(np.float32(b["c"])) + 0
+    # camera as written; the film's aspect decides the FoV axis (pbrt/mod.rs:807-816)
+    assert _f3(cam.position) == _f3(sd.camera["position"]) and _f3(cam.target) == _f3(sd.camera["target"])
+    assert np.float32(cam.fov_degrees) == np.float32(sd.camera["fov_degrees"])
+    # the independent loader reads the same files to the same scene
+    want, wcam, wres = cfg3_oracle_loaded
+    assert_same_scene(want, got)
+    assert_same_camera(wcam, cam, film, wres)
+    assert dt < 5.0
+
+
 # ----------------------------------------------------------------------------- GPU: load -> render
 @pytest.mark.gpu
 def test_loaded_pbrt_scene_renders_like_the_oracle(tmp_path, ol, oracle, yk, ctx):
@@ -319,3 +396,41 @@ def test_loaded_ply_scene_renders_like_the_oracle(tmp_path, ol, oracle, yk, ctx)
     want, rays = oracle.OracleScene(want_sd).render_tiles(cam.matrices, sampler, integ, tiles, n_threads=0)
     assert stats.rays == rays and np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert got.max() > 0.05
+
+
+@pytest.mark.gpu
+def test_cfg2_ply_file_renders_like_the_oracle(cfg2_ply, ol, oracle, yk, ctx):
+    """BASELINE configs[1] end to end from its file: yk_load_ply -> yk_scene_create -> Path 8, Uniform 16 spp, 1920 x 1080:
+    the first 96 spiral tiles equal the oracle's render of the scene oracle/loaders.py reads from the same file."""
+    got_sd, cam_p, film = loaders.load_ply(cfg2_ply)
+    want_sd, _, _ = ol.load_ply(cfg2_ply)
+    fs = yk.FilmSettings(res=(1920, 1080), tile_dim=film.tile_dim)
+    cam = yk.Camera(cam_p, fs)
+    tiles = yk.film_tiles(fs)[:96]
+    sampler = yk.SamplerType.Uniform(16, 0x73B9642E74AC471C)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=8))
+    sc = yk.Scene(ctx, got_sd)
+    got, stats = yk.IntegratorType.instantiate(ctx, integ).render_tiles(sc, cam, sampler, tiles)
+    want, rays = oracle.OracleScene(want_sd).render_tiles(cam.matrices, sampler, integ, tiles, n_threads=0)
+    sc.close()
+    assert stats.rays == rays and np.array_equal(got.view(np.uint32), want.view(np.uint32)) and got.max() > 0.05
+
+
+@pytest.mark.gpu
+def test_cfg3_pbrt_file_renders_like_the_oracle(cfg3_pbrt, cfg3_oracle_loaded, oracle, yk, ctx):
+    """BASELINE configs[2]'s shape end to end from files: yk_load_pbrt (802 PLY meshes) -> SAH BVH -> Path 8, Stratified 8 x 8,
+    1920 x 1080: the first 48 spiral tiles against the oracle's render of what oracle/loaders.py read, bit for bit."""
+    got_sd, cam_p, film = loaders.load_pbrt(cfg3_pbrt)
+    want_sd = cfg3_oracle_loaded[0]
+    fs = yk.FilmSettings(res=film.res, tile_dim=film.tile_dim)
+    cam = yk.Camera(cam_p, fs)
+    tiles = yk.film_tiles(fs)[:48]
+    sampler = yk.SamplerType.Stratified((8, 8), True, 0x73B9642E74AC471C)
+    integ = yk.IntegratorType.Path(yk.PathParams(max_depth=8))
+    sc = yk.Scene(ctx, got_sd)
+    got, stats = yk.IntegratorType.instantiate(ctx, integ).render_tiles(sc, cam, sampler, tiles)
+    osc = oracle.OracleScene(want_sd)
+    want, rays = osc.render_tiles(cam.matrices, sampler, integ, tiles, n_threads=0)
+    osc.close()
+    sc.close()
+    assert stats.rays == rays and np.array_equal(got.view(np.uint32), want.view(np.uint32)) and got.mean() > 0.01

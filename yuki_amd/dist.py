@@ -18,7 +18,8 @@ from . import abi
 
 
 def shard_tiles(tiles, rank, world):
-    """Tile i of the spiral order goes to rank i mod world."""
+    """Tile i of the spiral order goes to rank i mod world (for a whole film: yk_multi_deal, core.multi_deal — the same
+    deal behind the C ABI, which yk_multi_film_create uses; tests/test_multi_deal.py holds the two together)."""
     return np.ascontiguousarray(np.asarray(tiles, dtype=abi.TILE_DTYPE)[rank::world])
 
 

@@ -422,15 +422,24 @@ def _fit_unit(points64):
     return (s * p + s * (-center)).astype(F)
 
 
-def bunny_class(n=76, seed=0xB077E):
+def bunny_class_raw(n=76, seed=0xB077E):
+    """The mesh as a PLY file holds it: float32 vertices BEFORE Scene::ply's fit-to-unit-cube transform, and the faces
+    (tests/scene_files.py::write_cfg2_ply writes exactly this)."""
     sph, tris = _cube_sphere(n)
     disp = 1.0 + 0.15 * fractal_noise(sph * 2.5, seed, 3)
-    pts = _fit_unit(sph * disp[:, None])
+    raw = (sph * disp[:, None]).astype(F)
+    pts = _fit_unit(raw)
     # orient triangles outward (counter-clockwise seen from outside)
     p0, p1, p2 = pts[tris[:, 0]], pts[tris[:, 1]], pts[tris[:, 2]]
     nrm = np.cross(p1 - p0, p2 - p0)
     flip = (nrm * (p0 + p1 + p2)).sum(axis=1) < 0
     tris[flip] = tris[flip][:, [0, 2, 1]]
+    return raw, tris
+
+
+def bunny_class(n=76, seed=0xB077E):
+    raw, tris = bunny_class_raw(n, seed)
+    pts = _fit_unit(raw)
     nt = tris.shape[0]
     l2w, _ = _translation((5.0, 5.0, 0.0))
     return SceneData(
