@@ -90,6 +90,15 @@ def pmc_traffic(workload):
     return json.load(open(os.path.join(ROOT, "profiles", best))), f"profiles/{best}"
 
 
+def git_blob_hash(path):
+    """`git hash-object` of a tracked file, computed here (the GPU box has no .git): a line that quotes a stored PMC set names
+    the exact content it read, so a stale set is visible next to the commit the bench ran at."""
+    import hashlib
+
+    data = open(os.path.join(ROOT, path), "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -485,9 +494,10 @@ def main():
             # test, 36 B per triangle test (oracle counters) — are mostly L1 / LDS / L2 hits, not HBM bytes: they are
             # reported as `algorithmic`, never as an HBM fraction.
             pmc_d, pmc_src = pmc_traffic(args.workload)
-            if args.batch_paths:  # the tracked per-launch counters were collected with the default batch size: another one has other launches
-                log("[bench] --batch-paths given: the PMC-based roofline entries (traffic, TA busy, L1 / L2 rates) are left out")
+            if args.batch_paths or args.scene_file:  # the tracked per-launch counters were collected with the default batch size and the generated scene
+                log("[bench] --batch-paths / --scene-file given: the PMC-based roofline entries (traffic, TA busy, L1 / L2 rates) are left out")
                 pmc_d, pmc_src = {}, None
+            pmc_blob = git_blob_hash(pmc_src) if pmc_src else None
             table_bytes = int(info.n_interior) * 64 + int(info.n_shapes) * 48  # what the lanes gather from: 64-B nodes, 48-B triangles
             ceil_l1 = gather_ceiling(0)
             ceil_tab = gather_ceiling(table_bytes)
@@ -502,6 +512,7 @@ def main():
                     traffic = fam["fetch_size_bytes_per_launch"] + 0.5 * stream_bytes_per_unit * units / max(1, n_launch) + fam.get("write_size_bytes_per_launch", 0.0)
                 d = dict(bound="hbm", what="L2-miss (fabric-side) traffic incl. Infinity-Cache hits: PMC FETCH_SIZE (gathers at full size, + the uncounted half of the streamed ray records) + WRITE_SIZE per launch / live launch duration",
                          kernel=name, kernels=kernels, achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None, traffic=traffic, traffic_source=pmc_src,
+                         traffic_source_git_blob=pmc_blob,
                          avg_launch_ms=avg_s * 1e3, launches=n_launch, rays_per_launch=units / max(1, n_launch),
                          timing="one untimed probe step with overlap_shadow=0: every launch alone on the GPU, HIP events on its stream")
                 if traffic:
@@ -530,6 +541,13 @@ def main():
                                         addr_stalled_by_tc_frac=(fam.get("ta_addr_stalled_by_tc_per_launch", 0.0) / 256.0) / (fam["grbm_gui_active_per_launch"] / 8.0))
                 if fam.get("l2_read_bytes_per_launch"):
                     d["l2"] = dict(achieved=fam["l2_read_bytes_per_launch"] / avg_s / 1e9, peak=L2_PEAK_GBPS, unit="GB/s", frac=fam["l2_read_bytes_per_launch"] / avg_s / 1e9 / L2_PEAK_GBPS)
+                # `bound` names the roofline `frac` is taken against (HBM); `binding` names the unit the kernel is actually
+                # short of — the CU's vector-memory path — with its two measures side by side
+                d["binding"] = dict(unit="vector-memory (TA -> TCP -> L2 per-lane gathers)",
+                                    ta_busy_frac=d["ta_busy"]["frac"] if "ta_busy" in d else None,
+                                    active_lane_gather_frac=d["vector_memory"]["frac"] if "vector_memory" in d else None,
+                                    valu_lane_utilisation=fam.get("valu_lane_utilisation"),
+                                    note="ta_busy_frac: TA busy cycles per CU / launch cycles; active_lane_gather_frac: active-lane L1 accesses/s against the gather micro-benchmark's L1-resident rate")
                 return d
 
             alg_closest = alg_any = None

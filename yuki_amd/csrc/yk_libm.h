@@ -46,6 +46,9 @@ YK_HD double quadrant_reduce(double x, int& quadrant) {
 }
 
 YK_HD float det_sinf(float xf) {
+#if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)  // timing builds only: the hardware approximations instead of the f64 recipe
+    return __sinf(xf);
+#endif
     double x = (double)xf;
     if (!(fabs(x) < 1.0e300)) return xf - xf;
     int q;
@@ -55,6 +58,9 @@ YK_HD float det_sinf(float xf) {
 }
 
 YK_HD float det_cosf(float xf) {
+#if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)  // timing builds only: the hardware approximations instead of the f64 recipe
+    return __cosf(xf);
+#endif
     double x = (double)xf;
     if (!(fabs(x) < 1.0e300)) return xf - xf;
     int q;
@@ -64,6 +70,9 @@ YK_HD float det_cosf(float xf) {
 }
 
 YK_HD float det_tanf(float xf) {
+#if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)  // timing builds only: the hardware approximations instead of the f64 recipe
+    return __tanf(xf);
+#endif
     double x = (double)xf;
     if (!(fabs(x) < 1.0e300)) return xf - xf;
     int q;
@@ -73,6 +82,9 @@ YK_HD float det_tanf(float xf) {
 }
 
 YK_HD float det_logf(float xf) {
+#if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)  // timing builds only: the hardware approximations instead of the f64 recipe
+    return __logf(xf);
+#endif
     if (xf != xf) return xf;
     if (xf < 0.0f) return (xf - xf) / 0.0f;
     if (xf == 0.0f) return -1.0f / 0.0f;

@@ -37,6 +37,9 @@ YK_HD u64 rotl64(u64 x, int b) { return (x << b) | (x >> (64 - b)); }
 // n_words full words m0,m1 followed by `tail` (remaining bytes, little endian)
 // for a message of total_len bytes.
 YK_HD u64 siphash13_words(int n_words, u64 m0, u64 m1, u64 tail, unsigned total_len) {
+#ifdef YK_ABLATE_HASH  // timing builds only (tools/gpu_shade_ablation.sh): what the sampler's SipHash-1-3 costs; the image changes
+    return (m0 * 0x9E3779B97F4A7C15ull) ^ (m1 + tail + total_len + (unsigned)n_words);
+#endif
     u64 v0 = 0x736f6d6570736575ULL, v1 = 0x646f72616e646f6dULL, v2 = 0x6c7967656e657261ULL, v3 = 0x7465646279746573ULL;
     if (n_words > 0) {
         v3 ^= m0;
