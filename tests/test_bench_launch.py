@@ -51,3 +51,26 @@ def test_self_launched_ranks_render_the_same_film():
     assert b["extra"]["film_mean_rgb"] == a["extra"]["film_mean_rgb"]
     assert b["extra"]["rays_per_step"] == a["extra"]["rays_per_step"]
     assert a["roofline"] is None or a["roofline"]["frac"] is None or a["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.gpu
+def test_scene_file_workload(tmp_path):
+    """`bench.py --scene-file`: BASELINE configs[1] from the PLY file its text names (tests/scene_files.py writes the generated
+    mesh as Scene::ply reads it) — the same triangles, ray count and film as the generated workload, the file's load time
+    reported, and a roofline without the stored PMC entries (they belong to the generated scene's launches)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scene_files as sf
+
+    p = sf.write_cfg2_ply(str(tmp_path / "bunny_class.ply"))
+    gen = _run(["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--workload", "cfg2"])
+    assert gen.returncode == 0, gen.stderr[-2000:]
+    got = _run(["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--workload", "cfg2", "--scene-file", p])
+    assert got.returncode == 0, got.stderr[-2000:]
+    a, b = json.loads(gen.stdout), json.loads(got.stdout)
+    assert b["config"]["triangles"] == a["config"]["triangles"] == 69312
+    assert "scene file bunny_class.ply" in b["config"]["workload"] and b["extra"]["scene_load_s"] is not None
+    assert b["extra"]["rays_per_step"] == a["extra"]["rays_per_step"] and b["extra"]["film_mean_rgb"] == a["extra"]["film_mean_rgb"]
+    assert b["roofline"] is None or b["roofline"]["traffic"] is None
+    if a["roofline"] is not None:  # the generated workload quotes a tracked PMC set and names its content
+        assert a["roofline"]["traffic_source"].startswith("profiles/") and len(a["roofline"]["traffic_source_git_blob"]) == 40
+        assert a["roofline"]["binding"]["unit"].startswith("vector-memory")

@@ -435,6 +435,10 @@ def test_cancellation_at_the_references_granularity(yk, cfg3_scene):
     assert full_st is None
     got, st = yk.IntegratorType.instantiate(c, small_integ).render_tiles(sc, yk.Camera(sd.camera, small), small_sampler, yk.film_tiles(small))
     assert st.rays == st_want.rays and np.array_equal(_bits(got), _bits(want))
+    # an interruption that finds nothing in flight is consumed by the next submission's start, not by its kernels
+    c.interrupt()
+    got, st = yk.IntegratorType.instantiate(c, small_integ).render_tiles(sc, yk.Camera(sd.camera, small), small_sampler, yk.film_tiles(small))
+    assert st.rays == st_want.rays and np.array_equal(_bits(got), _bits(want))
     sc.close()
     fsc.close()
     c.close()

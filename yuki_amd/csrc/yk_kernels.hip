@@ -144,9 +144,10 @@ __global__ void k_raygen_user(RenderParams prm, const float* ray_o, const float*
 // "dequeue") and made this kernel atomic-bound (profiles/r01_a_*: 0.178 s/frame,
 // 79 % of wave cycles waiting).
 #ifndef SHADE_CAP
-#define SHADE_CAP 335  // staged continuation paths per block (64 B each).  With SHADE_CAPQ and the sort window's order table the block's LDS is
-                       // 53248 B: three blocks per CU.  The cliff was measured, not computed: 53296 B runs three blocks, 53312 B (one more
-                       // word, round 3's interruption flag) ran two and cost 4.6 ms of 30.6 per frame — hence 335, not 336
+#define SHADE_CAP 335  // staged continuation paths per block (64 B each).  With SHADE_CAPQ, the sort window's order table and the round-3
+                       // interruption flag the block's LDS is 53248 B: three blocks per CU (LDS is handed out in 1280-byte granules on gfx950:
+                       // 42 granules = 53760 B x 3 fit 160 KB, one granule more does not).  335, not 336: the flag word would have made it
+                       // 53312 B — inside the same 42 granules on paper, but only 53248 and 53296 are measured sizes
 #endif
 #ifndef SHADE_CAPQ
 #define SHADE_CAPQ 768  // staged shadow rays per block (36 B each): a whole iteration of 256 paths x 3 lights fits
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, R
     // iterations per window: a full queue sorts win_max (<= SHADE_WIN) x 256 paths together; a queue too short to give every
     // resident block (`block_slots` of them on the device) a full window takes shorter ones, down to one iteration
     const unsigned win_iters = min(win_max, max(1u, bc[0] / (BLOCK * block_slots)));
-    static_assert(sizeof(ShadeStaging<CAP, CAPQ>) <= 53296, "k_shade: 53312 bytes of LDS per block were measured to cost the third block per CU");
+    static_assert(sizeof(ShadeStaging<CAP, CAPQ>) <= 53296, "k_shade: more LDS than the measured 53296 bytes per block (42 granules = 53760 cost the third block per CU)");
     __shared__ ShadeStaging<CAP, CAPQ> stg;
     const unsigned nl = sc.n_lights;
     unsigned* next_count = bc + YK_CTRL_STRIDE;
