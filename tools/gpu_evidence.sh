@@ -1,18 +1,19 @@
 #!/bin/bash
+# The round's evidence set on one GPU box: GPU suite, bench lines of every single-GPU workload, cfg5's profile set.
+# (cfg3's and cfg2's sets: tools/profile_round.sh r03_a cfg3 / r03_c cfg2, run separately.)  bash tools/gpu_evidence.sh <tag, e.g. r03>
+T=${1:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd $R
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/r02_pytest_gpu_final.log 2>&1 || { tail -40 $O/r02_pytest_gpu_final.log; exit 1; }
-tail -2 $O/r02_pytest_gpu_final.log
-bash tools/profile_round.sh r02_a cfg3
-cp $O/r02_a_pmc_cfg3.json profiles/
-python3 bench.py --steps 5 > $O/r02_a_bench.json 2> $O/r02_a_bench.log
-python3 bench.py --steps 5 --no-cpu-baseline --two-in-flight > $O/r02_a_two_in_flight.json 2>> $O/r02_a_bench.log
-bash tools/profile_round.sh r02_b cfg5
-cp $O/r02_b_pmc_cfg5.json profiles/
-python3 bench.py --workload cfg5 --steps 3 > $O/r02_b_bench.json 2> $O/r02_b_bench.log
-python3 bench.py --workload cfg2 --steps 5 > $O/r02_c_bench_cfg2.json 2> $O/r02_c_bench_cfg2.log
-python3 bench.py --workload cfg1 --steps 20 > $O/r02_c_bench_cfg1.json 2> $O/r02_c_bench_cfg1.log
-python3 bench.py --rccl-single --steps 5 --no-cpu-baseline > $O/r02_d_rccl_single_abi.json 2> $O/r02_d_rccl_single_abi.log
-python3 bench.py --rccl-single --gather torch --steps 5 --no-cpu-baseline > $O/r02_d_rccl_single_torch.json 2> $O/r02_d_rccl_single_torch.log
-python3 bench.py --gpus 2 --steps 2 > $O/r02_d_gpus2.json 2> $O/r02_d_gpus2.log; echo "gpus2 rc=$?" >> $O/r02_d_gpus2.log
-ls $O | grep "r02_[a-d]"
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/${T}_pytest_gpu_final.log 2>&1 || { tail -40 $O/${T}_pytest_gpu_final.log; exit 1; }
+tail -2 $O/${T}_pytest_gpu_final.log
+python3 bench.py --steps 5 > $O/${T}_a_bench.json 2> $O/${T}_a_bench.log
+python3 bench.py --steps 5 --sync-steps --no-cpu-baseline > $O/${T}_a_bench_sync.json 2>> $O/${T}_a_bench.log
+python3 bench.py --workload cfg2 --steps 5 > $O/${T}_c_bench_cfg2.json 2> $O/${T}_c_bench_cfg2.log
+python3 bench.py --workload cfg1 --steps 20 > $O/${T}_c_bench_cfg1.json 2> $O/${T}_c_bench_cfg1.log
+python3 bench.py --rccl-single --steps 5 --no-cpu-baseline > $O/${T}_d_rccl_single_abi.json 2> $O/${T}_d_rccl_single_abi.log
+python3 bench.py --gpus 2 --steps 2 > $O/${T}_d_gpus2.json 2> $O/${T}_d_gpus2.log; echo "gpus2 rc=$?" >> $O/${T}_d_gpus2.log
+python3 tools/write_scene_files.py cfg3 /tmp/yk_cfg3_files > /tmp/yk_cfg3_path.txt 2> $O/${T}_e_scene_file.log
+python3 bench.py --scene-file $(cat /tmp/yk_cfg3_path.txt) --steps 3 --no-cpu-baseline > $O/${T}_e_bench_scene_file.json 2>> $O/${T}_e_scene_file.log
+[ -n "$SKIP_CFG5_PROFILE" ] || bash tools/profile_round.sh ${T}_b cfg5
+python3 bench.py --workload cfg5 --steps 3 > $O/${T}_b_bench.json 2> $O/${T}_b_bench.log
+ls $O | grep "${T}_[a-e]"

@@ -75,8 +75,7 @@ yk_status yk_context_create(int device, yk_context** out) {
             ctx->cancel_host = static_cast<unsigned*>(host_word);
             ctx->cancel_host_dev = static_cast<const unsigned*>(dev_word);
             std::memset(host_word, 0, 128);
-            ctx->cancel_host[16] = 1u;
-            if (hipStreamCreateWithFlags(&ctx->cancel_stream, hipStreamNonBlocking) != hipSuccess) ctx->cancel_stream = nullptr;
+            ctx->cancel_host[16] = 1u;  // (the stream that carries it is made when the first interruption needs it: a context holds no idle streams, see above)
         } else {
             (void)hipHostFree(host_word);
         }

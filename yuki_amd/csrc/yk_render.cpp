@@ -266,6 +266,7 @@ static void raise_cancel(yk_context* ctx, bool from_render_thread = true) {
     ctx->cancel_raised.store(true, std::memory_order_release);
     __atomic_store_n(ctx->cancel_host, 1u, __ATOMIC_RELEASE);
     // ... and the device word directly (a copy engine's job: it does not queue behind the kernels): k_shade looks at this one only
+    if (from_render_thread && !ctx->cancel_stream && hipStreamCreateWithFlags(&ctx->cancel_stream, hipStreamNonBlocking) != hipSuccess) ctx->cancel_stream = nullptr;
     if (from_render_thread && ctx->cancel_stream && ctx->counters.p)
         (void)hipMemcpyAsync(error_block(ctx) + YK_CTRL_CANCELLED, ctx->cancel_host + 16, 4, hipMemcpyHostToDevice, ctx->cancel_stream);
 }
@@ -438,6 +439,18 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         HIP_TRY(ctx, hipEventCreate(&ev1));
         HIP_TRY(ctx, hipEventRecord(ev0, st));
     }
+#ifdef YK_EXPERIMENT_GRAPH  // timing builds only (tools/graph_tile_bench.py): what a hipGraph of a small job's ~40 dependent launches returns.
+                            // YK_GRAPH_REPLAY=N: the job's launches are captured into a graph once and the graph is launched N times; stats->seconds_total
+                            // becomes the time of ONE replay.  Needs a job that enqueues without host synchronisation (one tile, or a prepared list)
+                            // whose buffers exist already (a plain call first).
+    const int graph_replay = std::getenv("YK_GRAPH_REPLAY") ? std::atoi(std::getenv("YK_GRAPH_REPLAY")) : 0;  // read per call: the tool sets it after a plain warm-up call
+    const bool capturing = graph_replay > 0 && stats != nullptr && !cancel;
+    if (capturing) {
+        kt.on = false;
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    }
+#endif
     uint32_t n_batches = 0, n_trace = 0, n_shadow = 0;
     float* out = reinterpret_cast<float*>(d_out_rgb);
 
@@ -555,6 +568,34 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         t_begin = t_end;
     }
     HIP_TRY(ctx, hipGetLastError());
+#ifdef YK_EXPERIMENT_GRAPH
+    if (capturing) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIP_TRY(ctx, hipStreamEndCapture(st, &graph));
+        HIP_TRY(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIP_TRY(ctx, hipGraphLaunch(exec, st));  // warm
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        hipEvent_t g0, g1;
+        HIP_TRY(ctx, hipEventCreate(&g0));
+        HIP_TRY(ctx, hipEventCreate(&g1));
+        const double w0 = now_seconds();
+        HIP_TRY(ctx, hipEventRecord(g0, st));
+        for (int k = 0; k < graph_replay; ++k) HIP_TRY(ctx, hipGraphLaunch(exec, st));
+        HIP_TRY(ctx, hipEventRecord(g1, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        const double w1 = now_seconds();
+        float gms = 0.0f;
+        (void)hipEventElapsedTime(&gms, g0, g1);
+        std::fprintf(stderr, "graph replay: %d launches of the captured job, %.4f ms each on the device, %.4f ms each on the host clock\n", graph_replay, gms / graph_replay,
+                     (w1 - w0) * 1e3 / graph_replay);
+        (void)hipEventDestroy(g0);
+        (void)hipEventDestroy(g1);
+        (void)hipGraphExecDestroy(exec);
+        (void)hipGraphDestroy(graph);
+        HIP_TRY(ctx, hipEventRecord(ev0, st));
+    }
+#endif
     if (stats) {
         HIP_TRY(ctx, hipEventRecord(ev1, st));
         // a synchronous call: the predicate is polled while the GPU works
