@@ -114,6 +114,8 @@ class Context {
     Context& operator=(const Context&) = delete;
     yk_context* handle() const { return h_; }
     void set_option(const char* key, int64_t v) { check(yk_context_set_option(h_, key, v), h_); }
+    // stop what the context has enqueued (any thread; yk_cancel_fn in yuki_hip.h)
+    void interrupt() { check(yk_context_interrupt(h_), h_); }
 
    private:
     yk_context* h_ = nullptr;
@@ -219,7 +221,14 @@ class Integrator {
 // film.rs:210-282: the write-back).  devices[0] assembles the film.
 class Node {
    public:
-    explicit Node(const std::vector<int>& devices) { check(yk_multi_create(devices.data(), (uint32_t)devices.size(), &m_)); }
+    // flags: YK_MULTI_SHARED_DEVICES (ranks may name the same device: G ranks on one GPU), YK_MULTI_PEER_COPY (hipMemcpyPeerAsync instead of RCCL)
+    explicit Node(const std::vector<int>& devices, uint32_t flags = 0) { check(yk_multi_create_ex(devices.data(), (uint32_t)devices.size(), flags, &m_)); }
+    // the tiles of rank `rank` among `n_ranks` (render_manager.rs:206-210: spiral tile i -> rank i mod n_ranks); needs no device
+    static std::vector<yk_tile> deal(const FilmSettings& fs, uint32_t n_ranks, uint32_t rank, uint64_t* pixels = nullptr) {
+        std::vector<yk_tile> t(yk_multi_deal(fs.res_x, fs.res_y, fs.tile_dim, n_ranks, rank, nullptr, 0, nullptr));
+        yk_multi_deal(fs.res_x, fs.res_y, fs.tile_dim, n_ranks, rank, t.data(), t.size(), pixels);
+        return t;
+    }
     ~Node() {
         if (film_) yk_multi_film_destroy(film_);
         if (scene_) yk_multi_scene_destroy(scene_);
@@ -246,6 +255,14 @@ class Node {
                                 void* user = nullptr) {
         yk_render_stats st{};
         mcheck(yk_multi_render_film(m_, scene_, &camera.matrices, &sampler, &integrator, film_, film_rgb, &st, cancel, user));
+        return st;
+    }
+    // the accumulating film over all devices (film.rs:260-272): passes first_sample .. + n_passes - 1 of every tile, added on device 0
+    void clear_film() { mcheck(yk_multi_film_clear(m_, film_)); }
+    yk_render_stats accumulate_film(const Camera& camera, const yk_sampler_desc& sampler, const yk_integrator_desc& integrator, uint32_t first_sample, uint32_t n_passes,
+                                    float* film_rgb, yk_cancel_fn cancel = nullptr, void* user = nullptr) {
+        yk_render_stats st{};
+        mcheck(yk_multi_accumulate_film(m_, scene_, &camera.matrices, &sampler, &integrator, film_, first_sample, n_passes, film_rgb, &st, cancel, user));
         return st;
     }
 

@@ -129,6 +129,26 @@ int main(int argc, char** argv) {
         } catch (const Error& e) {
             std::printf("node_dup=status%d\n", (int)e.status);
         }
+        // three virtual ranks on device 0 (YK_MULTI_SHARED_DEVICES): the same film; then the accumulating film, 2 + 2 passes = 4 x the plain one
+        Node three({0, 0, 0}, YK_MULTI_SHARED_DEVICES);
+        three.set_scene(d);
+        three.set_film(fs);
+        std::vector<float> v3(whole.size());
+        yk_render_stats m3 = three.render_film(cam, smp, IntegratorType::Path(PathParams{6, false, 0.0f}), v3.data());
+        std::printf("virtual_ranks_match=%d\n", (m3.rays == st.rays && std::memcmp(v3.data(), ref.data(), v3.size() * 4) == 0) ? 1 : 0);
+        three.clear_film();
+        three.accumulate_film(cam, smp, IntegratorType::Path(PathParams{6, false, 0.0f}), 0, 2, nullptr);
+        three.accumulate_film(cam, smp, IntegratorType::Path(PathParams{6, false, 0.0f}), 2, 2, v3.data());
+        bool acc_ok = true;
+        for (size_t k = 0; k < v3.size(); ++k) acc_ok = acc_ok && (v3[k] / 4.0f == ref[k]);
+        std::printf("virtual_ranks_accumulate=%d\n", acc_ok ? 1 : 0);
+        uint64_t px = 0, total = 0;
+        size_t n_tiles = 0;
+        for (uint32_t r = 0; r < 3; ++r) {
+            n_tiles += Node::deal(fs, 3, r, &px).size();
+            total += px;
+        }
+        std::printf("deal_covers_film=%d\n", (n_tiles == tiles.size() && total == (uint64_t)fs.res_x * fs.res_y) ? 1 : 0);
     }
     try {
         FilmTile bad{8, 8, 8, 12};

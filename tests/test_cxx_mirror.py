@@ -58,3 +58,5 @@ def test_cxx_mirror_renders(tmp_path):
     assert kv["bad_tile"] == "status1"
     assert kv["accumulate_matches_plain"] == "1"
     assert kv["node_rays_match"] == "1" and kv["node_film_matches"] == "1" and kv["node_devices"] == "1" and kv["node_dup"] == "status1"
+    # three virtual ranks on one device, the accumulating film over them, the device-free deal
+    assert kv["virtual_ranks_match"] == "1" and kv["virtual_ranks_accumulate"] == "1" and kv["deal_covers_film"] == "1"
