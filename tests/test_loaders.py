@@ -5,6 +5,8 @@ Parity unpinned: the reference holds no tests or sample files for its loaders, s
 sides follow its source text (scene/ply.rs, scene/pbrt/*.rs); what these tests pin is
 that the two independent implementations agree exactly, plus the behaviours spelled
 out in the reference (quirks included)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -355,6 +357,32 @@ def test_cfg3_pbrt_file_loads_to_the_generators_arrays(cfg3_pbrt, cfg3_scene, cf
     assert_same_scene(want, got)
     assert_same_camera(wcam, cam, film, wres)
     assert dt < 5.0
+    # the PLY files are read in parallel after the parse (pbrt/mod.rs:786-800); one thread gives the same scene
+    os.environ["YK_LOADER_THREADS"] = "1"
+    try:
+        serial, _, _ = loaders.load_pbrt(cfg3_pbrt)
+    finally:
+        del os.environ["YK_LOADER_THREADS"]
+    assert_same_scene(serial, got)
+
+
+def test_pbrt_parse_error_after_a_broken_ply_wins(tmp_path):
+    """The reference reads `plymesh` files AFTER the parse (pbrt/mod.rs:786-800), so an unknown directive further down the file is
+    what the load reports; a missing file ends the load where it is named (canonicalize(), :689-699)."""
+    (tmp_path / "bad.ply").write_bytes(b"ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nend_header\n0\n")
+    p = tmp_path / "s.pbrt"
+    p.write_text('WorldBegin\nShape "plymesh" "string filename" "bad.ply"\nObjectBegin "x"\nWorldEnd\n')
+    with pytest.raises(YukiError) as e:
+        loaders.load_pbrt(str(p))
+    assert "UnimplementedToken" in str(e.value) or "ObjectBegin" in str(e.value)
+    p.write_text('WorldBegin\nShape "plymesh" "string filename" "bad.ply"\nWorldEnd\n')
+    with pytest.raises(YukiError) as e:
+        loaders.load_pbrt(str(p))
+    assert "PLY" in str(e.value)
+    p.write_text('WorldBegin\nShape "plymesh" "string filename" "missing.ply"\nObjectBegin "x"\nWorldEnd\n')
+    with pytest.raises(YukiError) as e:
+        loaders.load_pbrt(str(p))
+    assert "Could not open" in str(e.value)
 
 
 # ----------------------------------------------------------------------------- GPU: load -> render

@@ -17,9 +17,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <atomic>
 #include <map>
+#include <thread>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -210,8 +213,13 @@ struct PlyReader {
 
 }  // namespace
 
-// ply::load (scene/ply.rs:19-130).  `fit`: no transform given -> scale/translate into the unit cube.
-static yk_status load_ply_mesh(const std::string& path, const Xf* transform, yk_loaded_scene& s, int material) {
+// The payload of one PLY file as ply::load reads it (scene/ply.rs:19-130), before any transform.  Pure: touches nothing but its
+// arguments (errors come back through the thread-local loader error of the CALLING thread), so several files are read at once.
+struct PlyMesh {
+    std::vector<float> pts, nrm, uv;
+    std::vector<uint32_t> indices;
+};
+static yk_status read_ply_mesh(const std::string& path, PlyMesh& out) {
     std::vector<unsigned char> buf;
     if (!read_file(path, buf)) return lfail(YK_ERR_INVALID_ARGUMENT, "Could not open '" + path + "'");
     // ---- header
@@ -280,8 +288,8 @@ static yk_status load_ply_mesh(const std::string& path, const Xf* transform, yk_
         return lfail(YK_ERR_UNSUPPORTED, "PLY: Unsupported content");
     // ---- payload
     PlyReader rd(buf, pos, format);
-    std::vector<float> pts, nrm, uv;
-    std::vector<uint32_t> indices;
+    std::vector<float>&pts = out.pts, &nrm = out.nrm, &uv = out.uv;
+    std::vector<uint32_t>& indices = out.indices;
     bool saw_normal = false, saw_uv = false;
     for (const PlyElement& e : elements) {
         const bool is_v = &e == ve, is_f = &e == fe;
@@ -343,6 +351,13 @@ static yk_status load_ply_mesh(const std::string& path, const Xf* transform, yk_
         if (q >= nv) return lfail(YK_ERR_INVALID_ARGUMENT, "PLY: vertex index out of range");
     if (saw_normal && nrm.size() != pts.size()) return lfail(YK_ERR_INVALID_ARGUMENT, "PLY: normals on a subset of the vertices");
     if (saw_uv && uv.size() / 2 != nv) return lfail(YK_ERR_INVALID_ARGUMENT, "PLY: uvs on a subset of the vertices");
+    return YK_OK;
+}
+
+// Mesh::new for a PLY payload.  No transform given (Scene::ply): scale / translate into the unit cube (ply.rs:99-108).
+static void add_ply_mesh(yk_loaded_scene& s, const PlyMesh& m, const Xf* transform, int material) {
+    const std::vector<float>& pts = m.pts;
+    const size_t nv = pts.size() / 3;
     Xf t;
     if (transform) {
         t = *transform;
@@ -358,7 +373,14 @@ static yk_status load_ply_mesh(const std::string& path, const Xf* transform, yk_
         float mesh_scale = 1.0f / rmax(dg[0], rmax(dg[1], dg[2]));
         t = xf_mul(xf_scale(mesh_scale, mesh_scale, mesh_scale), xf_translation(-center[0], -center[1], -center[2]));
     }
-    add_mesh(s, t, indices, pts, nrm, uv, material);
+    add_mesh(s, t, m.indices, pts, m.nrm, m.uv, material);
+}
+
+static yk_status load_ply_mesh(const std::string& path, const Xf* transform, yk_loaded_scene& s, int material) {
+    PlyMesh m;
+    yk_status st = read_ply_mesh(path, m);
+    if (st != YK_OK) return st;
+    add_ply_mesh(s, m, transform, material);
     return YK_OK;
 }
 
@@ -620,7 +642,22 @@ static int sat_i32(double v) {
     return (int)v;
 }
 
+// scene/pbrt/mod.rs: ParseShape — shapes in file order; `plymesh` files are read after the parse, in parallel (:786-800)
+struct ParseShape {
+    int kind = 0;  // 0 sphere, 1 trianglemesh, 2 plymesh
+    yk_sphere_desc sphere;
+    Xf transform;
+    int material = 0;
+    std::vector<uint32_t> idx;
+    std::vector<float> P, N, UV;
+    std::string ply_path;
+    PlyMesh ply;
+    yk_status status = YK_OK;
+    std::string error;
+};
+
 struct PbrtState {
+    std::vector<ParseShape> shapes;
     Xf current = xf_identity();
     std::vector<Xf> xf_stack;
     std::vector<int> gs_stack;      // GraphicsState = the current material
@@ -905,8 +942,10 @@ static yk_status load_pbrt_file(const std::string& path, yk_loaded_scene& s, Pbr
                     std::memcpy(sp.world_to_object, S.current.mi, 64);
                     sp.radius = ps.f32("radius", 1.0f);
                     sp.material = S.cur_material;
-                    s.shape_order.push_back(0x80000000u | (uint32_t)s.spheres.size());
-                    s.spheres.push_back(sp);
+                    ParseShape ph;
+                    ph.kind = 0;
+                    ph.sphere = sp;
+                    S.shapes.push_back(std::move(ph));
                 } else if (shape_type == "trianglemesh") {
                     std::vector<uint32_t> idx;
                     if (auto ii = ps.ints.many("indices"))
@@ -922,13 +961,27 @@ static yk_status load_pbrt_file(const std::string& path, yk_loaded_scene& s, Pbr
                         if (q >= nv) throw fail(YK_ERR_INVALID_ARGUMENT, "pbrt: trianglemesh index out of range");
                     if (!N.empty() && N.size() != P.size()) throw fail(YK_ERR_INVALID_ARGUMENT, "pbrt: N count differs from P");
                     if (!UV.empty() && UV.size() / 2 != nv) throw fail(YK_ERR_INVALID_ARGUMENT, "pbrt: uv count differs from P");
-                    add_mesh(s, S.current, idx, P, N, UV, S.cur_material);
+                    ParseShape ph;
+                    ph.kind = 1;
+                    ph.transform = S.current;
+                    ph.material = S.cur_material;
+                    ph.idx = std::move(idx);
+                    ph.P = std::move(P);
+                    ph.N = std::move(N);
+                    ph.UV = std::move(UV);
+                    S.shapes.push_back(std::move(ph));
                 } else if (shape_type == "plymesh") {
                     std::string fn = ps.str("filename", "");
                     if (fn.empty()) throw fail(YK_ERR_INVALID_ARGUMENT, "Empty PLY filename");
-                    Xf tr = S.current;
-                    yk_status st = load_ply_mesh(parent + "/" + fn, &tr, s, S.cur_material);
-                    if (st != YK_OK) return st;
+                    // the path is resolved while parsing (canonicalize(): a missing file ends the load here, pbrt/mod.rs:689-699);
+                    // the file is READ after the parse, with the others
+                    ParseShape ph;
+                    ph.kind = 2;
+                    ph.transform = S.current;
+                    ph.material = S.cur_material;
+                    ph.ply_path = parent + "/" + fn;
+                    if (!std::ifstream(ph.ply_path, std::ios::binary).good()) return lfail(YK_ERR_INVALID_ARGUMENT, "Could not open '" + ph.ply_path + "'");
+                    S.shapes.push_back(std::move(ph));
                 }  // other shapes: "Unsupported shape type", skipped
             } else if (d == "Texture") {
                 std::string name = str(), ttype = str(), cls = str();
@@ -1032,6 +1085,77 @@ yk_status yk_load_pbrt(const char* path, uint32_t split_method, uint32_t max_sha
         st = load_pbrt_file(path, *s, S, 0);
     } catch (const std::exception& e) {
         st = lfail(YK_ERR_INVALID_ARGUMENT, std::string("pbrt: ") + e.what());
+    }
+    if (st == YK_OK) {
+        // "load plys" (pbrt/mod.rs:786-800: parse_shapes.par_iter_mut().try_for_each(ply::load)): the files are read by a few
+        // threads, each into its own ParseShape; the meshes then join the scene in file order ("collect meshes", :807-822)
+        std::vector<size_t> ply;
+        for (size_t i = 0; i < S.shapes.size(); ++i)
+            if (S.shapes[i].kind == 2) ply.push_back(i);
+        unsigned n_threads = (unsigned)std::min<size_t>(ply.size(), std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+        if (const char* e = std::getenv("YK_LOADER_THREADS")) n_threads = (unsigned)std::min<size_t>(ply.size(), (size_t)std::max(1, std::atoi(e)));  // measurements
+        std::atomic<size_t> next_ply{0};
+        auto work = [&]() {
+            for (;;) {
+                const size_t k = next_ply.fetch_add(1);
+                if (k >= ply.size()) return;
+                ParseShape& ph = S.shapes[ply[k]];
+                try {
+                    ph.status = read_ply_mesh(ph.ply_path, ph.ply);
+                    if (ph.status != YK_OK) ph.error = g_loader_error;  // this thread's own copy
+                } catch (const std::exception& e) {  // e.g. bad_alloc on an absurd element count
+                    ph.status = YK_ERR_INVALID_ARGUMENT;
+                    ph.error = std::string("PLY: ") + e.what();
+                }
+            }
+        };
+        if (n_threads <= 1) {
+            work();
+        } else {
+            std::vector<std::thread> pool;
+            try {
+                for (unsigned t = 0; t < n_threads; ++t) pool.emplace_back(work);
+            } catch (const std::exception&) {  // no more threads: the ones that started (and this one) finish the list
+            }
+            work();
+            for (std::thread& t : pool) t.join();
+        }
+        for (ParseShape& ph : S.shapes) {
+            if (ph.kind == 2 && ph.status != YK_OK) {  // the first failing file in file order
+                st = lfail(ph.status, ph.error);
+                break;
+            }
+        }
+    }
+    if (st == YK_OK) {
+        try {
+            size_t nv = 0, nt = 0;  // one allocation per array instead of a growth series (10 M triangles: cfg5)
+            for (const ParseShape& ph : S.shapes) {
+                nv += (ph.kind == 1 ? ph.P.size() : ph.ply.pts.size()) / 3;
+                nt += (ph.kind == 1 ? ph.idx.size() : ph.ply.indices.size()) / 3;
+            }
+            s->points.reserve(3 * nv);
+            s->normals.reserve(3 * nv);
+            s->uvs.reserve(2 * nv);
+            s->indices.reserve(3 * nt);
+            s->tri_mesh.reserve(nt);
+            s->tri_material.reserve(nt);
+            s->tri_area_light.reserve(nt);
+            s->shape_order.reserve(nt + S.shapes.size());
+            for (ParseShape& ph : S.shapes) {
+                if (ph.kind == 0) {
+                    s->shape_order.push_back(0x80000000u | (uint32_t)s->spheres.size());
+                    s->spheres.push_back(ph.sphere);
+                } else if (ph.kind == 1) {
+                    add_mesh(*s, ph.transform, ph.idx, ph.P, ph.N, ph.UV, ph.material);
+                } else {
+                    add_ply_mesh(*s, ph.ply, &ph.transform, ph.material);
+                    PlyMesh().pts.swap(ph.ply.pts);  // the payload has been copied into the scene
+                }
+            }
+        } catch (const std::exception& e) {
+            st = lfail(YK_ERR_INVALID_ARGUMENT, std::string("pbrt: ") + e.what());
+        }
     }
     if (st != YK_OK) {
         delete s;
