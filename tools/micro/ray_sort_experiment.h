@@ -113,3 +113,45 @@ inline Sorter& sorter() {
 }
 
 }  // namespace yk_exp
+
+// Expanded inside run_bounces (yk_render.cpp) after launch_shade of bounce b: uses its locals ctx, ws, st, bc, b, prm, pn, ds, cur.
+#define YK_SORT_AFTER_SHADE \
+        if (yk_exp::sorter().bounces > 0) { /* order the queues k_shade just wrote (synchronises: timing experiment) */ \
+            yk_exp::Sorter& S = yk_exp::sorter(); \
+            unsigned h[YK_CTRL_STRIDE + 1]; \
+            (void)hipStreamSynchronize(st); \
+            (void)hipMemcpy(h, bc, sizeof(h), hipMemcpyDeviceToHost); \
+            const unsigned n_next = h[YK_CTRL_STRIDE], n_sh = h[YK_CTRL_SHQ]; \
+            float ms_paths = 0.0f, ms_sh = 0.0f; \
+            if ((int)(b + 1) <= S.bounces && b + 1 < prm.max_depth && n_next > 1) { \
+                for (int k = 0; k < 4; ++k) (void)S.spare[k].ensure(ws.path[cur ^ 1u][k].bytes); \
+                (void)hipEventRecord(S.e0, st); \
+                const unsigned* order = S.sort(st, pn.rayO, pn.rayD, n_next, ds); \
+                PathBuffers sp; \
+                sp.rayO = S.spare[0].as<float4>(); \
+                sp.rayD = S.spare[1].as<float4>(); \
+                sp.thru = S.spare[2].as<float4>(); \
+                sp.rngs = S.spare[3].as<uint4>(); \
+                hipLaunchKernelGGL(yk_exp::k_permute_paths, dim3((n_next + 255) / 256), dim3(256), 0, st, order, n_next, pn, sp); \
+                (void)hipEventRecord(S.e1, st); \
+                (void)hipStreamSynchronize(st); \
+                (void)hipEventElapsedTime(&ms_paths, S.e0, S.e1); \
+                for (int k = 0; k < 4; ++k) std::swap(ws.path[cur ^ 1u][k], S.spare[k]); \
+            } \
+            if (S.shadow && (int)b < S.bounces && n_sh > 1) { \
+                (void)S.shO.ensure(ws.shO.bytes); \
+                (void)S.shD.ensure(ws.shD.bytes); \
+                (void)S.shq.ensure(ws.shq.bytes); \
+                (void)hipEventRecord(S.e0, st); \
+                const unsigned* order = S.sort(st, ws.shO.as<float4>(), ws.shD.as<float4>(), n_sh, ds); \
+                hipLaunchKernelGGL(yk_exp::k_permute_shadow, dim3((n_sh + 255) / 256), dim3(256), 0, st, order, n_sh, ws.shO.as<float4>(), ws.shD.as<float4>(), \
+                                   ws.shq.as<unsigned>(), S.shO.as<float4>(), S.shD.as<float4>(), S.shq.as<unsigned>()); \
+                (void)hipEventRecord(S.e1, st); \
+                (void)hipStreamSynchronize(st); \
+                (void)hipEventElapsedTime(&ms_sh, S.e0, S.e1); \
+                std::swap(ws.shO, S.shO); \
+                std::swap(ws.shD, S.shD); \
+                std::swap(ws.shq, S.shq); \
+            } \
+            std::fprintf(stderr, "  sort after shade %u: next queue %u rays %.3f ms | area-light shadow queue %u rays %.3f ms\n", b, n_next, ms_paths, n_sh, ms_sh); \
+        }

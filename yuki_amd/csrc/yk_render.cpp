@@ -23,6 +23,9 @@
 #ifdef YK_EXPERIMENT_SORT  // timing builds only (tools/build_variant.sh sort -DYK_EXPERIMENT_SORT): DESIGN.md §9
 #include "../../tools/micro/ray_sort_experiment.h"
 #endif
+#ifdef YK_EXPERIMENT_GRAPH
+#include "../../tools/micro/graph_replay_experiment.h"
+#endif
 
 // ------------------------------------------------------------------ render
 // ctx->counters: 8 x u64 (closest-hit rays, shadow rays, ...) followed by a 4-word error block whose word
@@ -175,46 +178,8 @@ void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* s
                      ws.shD.as<float4>(), ws.shC.as<float4>(), ws.vis.as<unsigned char>(), ws.shq.as<unsigned>(), ws.shO2.as<float4>(),
                      ws.shD2.as<float4>(), ws.shq2.as<unsigned>(), bc, split ? 1u : 0u, (b > 0 && ctx->shade_reorder) ? 1u : 0u, 3u * (unsigned)ctx->n_cu, sid_base, lean_origin);
         kt.end(e, 2, st);
-#ifdef YK_EXPERIMENT_SORT
-        if (yk_exp::sorter().bounces > 0) {  // order the queues k_shade just wrote (synchronises: timing experiment)
-            yk_exp::Sorter& S = yk_exp::sorter();
-            unsigned h[YK_CTRL_STRIDE + 1];
-            (void)hipStreamSynchronize(st);
-            (void)hipMemcpy(h, bc, sizeof(h), hipMemcpyDeviceToHost);
-            const unsigned n_next = h[YK_CTRL_STRIDE], n_sh = h[YK_CTRL_SHQ];
-            float ms_paths = 0.0f, ms_sh = 0.0f;
-            if ((int)(b + 1) <= S.bounces && b + 1 < prm.max_depth && n_next > 1) {
-                for (int k = 0; k < 4; ++k) (void)S.spare[k].ensure(ws.path[cur ^ 1u][k].bytes);
-                (void)hipEventRecord(S.e0, st);
-                const unsigned* order = S.sort(st, pn.rayO, pn.rayD, n_next, ds);
-                PathBuffers sp;
-                sp.rayO = S.spare[0].as<float4>();
-                sp.rayD = S.spare[1].as<float4>();
-                sp.thru = S.spare[2].as<float4>();
-                sp.rngs = S.spare[3].as<uint4>();
-                hipLaunchKernelGGL(yk_exp::k_permute_paths, dim3((n_next + 255) / 256), dim3(256), 0, st, order, n_next, pn, sp);
-                (void)hipEventRecord(S.e1, st);
-                (void)hipStreamSynchronize(st);
-                (void)hipEventElapsedTime(&ms_paths, S.e0, S.e1);
-                for (int k = 0; k < 4; ++k) std::swap(ws.path[cur ^ 1u][k], S.spare[k]);
-            }
-            if (S.shadow && (int)b < S.bounces && n_sh > 1) {
-                (void)S.shO.ensure(ws.shO.bytes);
-                (void)S.shD.ensure(ws.shD.bytes);
-                (void)S.shq.ensure(ws.shq.bytes);
-                (void)hipEventRecord(S.e0, st);
-                const unsigned* order = S.sort(st, ws.shO.as<float4>(), ws.shD.as<float4>(), n_sh, ds);
-                hipLaunchKernelGGL(yk_exp::k_permute_shadow, dim3((n_sh + 255) / 256), dim3(256), 0, st, order, n_sh, ws.shO.as<float4>(), ws.shD.as<float4>(),
-                                   ws.shq.as<unsigned>(), S.shO.as<float4>(), S.shD.as<float4>(), S.shq.as<unsigned>());
-                (void)hipEventRecord(S.e1, st);
-                (void)hipStreamSynchronize(st);
-                (void)hipEventElapsedTime(&ms_sh, S.e0, S.e1);
-                std::swap(ws.shO, S.shO);
-                std::swap(ws.shD, S.shD);
-                std::swap(ws.shq, S.shq);
-            }
-            std::fprintf(stderr, "  sort after shade %u: next queue %u rays %.3f ms | area-light shadow queue %u rays %.3f ms\n", b, n_next, ms_paths, n_sh, ms_sh);
-        }
+#ifdef YK_EXPERIMENT_SORT  // order the queues k_shade just wrote (synchronises: timing experiment, tools/micro/ray_sort_experiment.h)
+        YK_SORT_AFTER_SHADE
 #endif
         if (overlap) {
             (void)hipEventRecord(ws.ev_shade, st);
@@ -439,17 +404,8 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
         HIP_TRY(ctx, hipEventCreate(&ev1));
         HIP_TRY(ctx, hipEventRecord(ev0, st));
     }
-#ifdef YK_EXPERIMENT_GRAPH  // timing builds only (tools/graph_tile_bench.py): what a hipGraph of a small job's ~40 dependent launches returns.
-                            // YK_GRAPH_REPLAY=N: the job's launches are captured into a graph once and the graph is launched N times; stats->seconds_total
-                            // becomes the time of ONE replay.  Needs a job that enqueues without host synchronisation (one tile, or a prepared list)
-                            // whose buffers exist already (a plain call first).
-    const int graph_replay = std::getenv("YK_GRAPH_REPLAY") ? std::atoi(std::getenv("YK_GRAPH_REPLAY")) : 0;  // read per call: the tool sets it after a plain warm-up call
-    const bool capturing = graph_replay > 0 && stats != nullptr && !cancel;
-    if (capturing) {
-        kt.on = false;
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    }
+#ifdef YK_EXPERIMENT_GRAPH  // timing builds only (tools/micro/graph_replay_experiment.h)
+    YK_GRAPH_BEGIN
 #endif
     uint32_t n_batches = 0, n_trace = 0, n_shadow = 0;
     float* out = reinterpret_cast<float*>(d_out_rgb);
@@ -569,32 +525,7 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
     }
     HIP_TRY(ctx, hipGetLastError());
 #ifdef YK_EXPERIMENT_GRAPH
-    if (capturing) {
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        HIP_TRY(ctx, hipStreamEndCapture(st, &graph));
-        HIP_TRY(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        HIP_TRY(ctx, hipGraphLaunch(exec, st));  // warm
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        hipEvent_t g0, g1;
-        HIP_TRY(ctx, hipEventCreate(&g0));
-        HIP_TRY(ctx, hipEventCreate(&g1));
-        const double w0 = now_seconds();
-        HIP_TRY(ctx, hipEventRecord(g0, st));
-        for (int k = 0; k < graph_replay; ++k) HIP_TRY(ctx, hipGraphLaunch(exec, st));
-        HIP_TRY(ctx, hipEventRecord(g1, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        const double w1 = now_seconds();
-        float gms = 0.0f;
-        (void)hipEventElapsedTime(&gms, g0, g1);
-        std::fprintf(stderr, "graph replay: %d launches of the captured job, %.4f ms each on the device, %.4f ms each on the host clock\n", graph_replay, gms / graph_replay,
-                     (w1 - w0) * 1e3 / graph_replay);
-        (void)hipEventDestroy(g0);
-        (void)hipEventDestroy(g1);
-        (void)hipGraphExecDestroy(exec);
-        (void)hipGraphDestroy(graph);
-        HIP_TRY(ctx, hipEventRecord(ev0, st));
-    }
+    YK_GRAPH_END
 #endif
     if (stats) {
         HIP_TRY(ctx, hipEventRecord(ev1, st));

@@ -14,6 +14,9 @@
 #include "yk_device.h"
 #include "yk_geom.h"
 #include "yk_kernels.h"
+#ifdef YK_EXPERIMENT_XCD
+#include "../../tools/micro/xcd_claim_experiment.h"
+#endif
 #include "yk_wave.h"
 
 // build-time tuning knobs of the persistent traversal kernels
@@ -366,27 +369,8 @@ struct ChunkCursor {
             } else {
                 chunk = (unsigned)CHUNK;
                 base = 0;
-#ifdef YK_EXPERIMENT_XCD  // timing builds only: the queue cut into eight ranges, one per group of blocks that share an
-                          // XCD (blockIdx % 8, MI355X_MICROARCH.md); a wave claims from its own range (one atomic per claim, as before)
-                          // and moves on to the next range when that one is drained.  `head` points at eight words.
-                for (;;) {
-                    if (xcd_step >= 8u) {
-                        exhausted = true;
-                        return 0xffffffffu;
-                    }
-                    const unsigned y = ((blockIdx.x & 7u) + xcd_step) & 7u;
-                    const unsigned lo = (unsigned)((unsigned long long)n * y / 8ull), hi = (unsigned)((unsigned long long)n * (y + 1u) / 8ull);
-                    unsigned got = 0;
-                    if (lane_id() == 0) got = atomicAdd(head + y, chunk);
-                    got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
-                    if (got < hi - lo) {
-                        cur = lo + got;
-                        end = cur + chunk < hi ? cur + chunk : hi;
-                        break;
-                    }
-                    ++xcd_step;
-                }
-                goto claimed;
+#ifdef YK_EXPERIMENT_XCD  // timing builds only (tools/micro/xcd_claim_experiment.h): XCD-affine claims
+                YK_XCD_CLAIM
 #endif
                 if (lane_id() == 0) {
                     base = atomicAdd(head, chunk);
