@@ -38,7 +38,8 @@ def _worker(rank, world, port, out_path):
     cam = yk.Camera(sd.camera, fs)
     smp = abi.SamplerDesc(abi.SAMPLER_STRATIFIED, 2, 2, 1, SEED)
     integ = abi.IntegratorDesc(abi.INTEGRATOR_PATH, 6, 0, 0.0)
-    mine = ydist.shard_tiles(tiles, rank, world)
+    mine, my_px = yk.multi_deal(fs, world, rank)  # the C ABI's deal (yk_multi_deal: what yk_multi_film_create uses) ...
+    assert np.array_equal(mine, ydist.shard_tiles(tiles, rank, world)) and my_px == ydist.tile_pixels(mine)  # ... and bench.py's are one
     rgb, rays = oracle.OracleScene(sd).render_tiles(cam.matrices, smp, integ, mine, n_threads=1)
     slab = torch.zeros(ydist.slab_pixels(tiles, world) * 3, dtype=torch.float32)
     slab[: rgb.size] = torch.from_numpy(rgb.reshape(-1))
