@@ -482,6 +482,9 @@ yk_status yk_multi_accumulate_film(yk_multi* m, const yk_multi_scene* scene, con
                                    const yk_integrator_desc* integrator, yk_multi_film* film, uint32_t first_sample, uint32_t n_passes,
                                    float* film_rgb, yk_render_stats* stats, yk_cancel_fn cancel, void* user);
 yk_status yk_multi_film_clear(yk_multi* m, yk_multi_film* film);
+/* yk_context_interrupt on every rank's context: stops a frame in flight from any thread (the frame's call returns
+ * YK_ERR_CANCELLED if it was synchronous); the next frame is unaffected. */
+yk_status yk_multi_interrupt(yk_multi* m);
 yk_status yk_multi_sync(yk_multi* m);
 
 /* One process per GPU (MPI-style hosts, torch.distributed launchers): the same exchange between

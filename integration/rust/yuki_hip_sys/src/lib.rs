@@ -281,6 +281,7 @@ extern "C" {
     pub fn yk_multi_render_film(m: *mut yk_multi, scene: *const yk_multi_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, film: *mut yk_multi_film, film_rgb: *mut f32, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
     pub fn yk_multi_accumulate_film(m: *mut yk_multi, scene: *const yk_multi_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, film: *mut yk_multi_film, first_sample: u32, n_passes: u32, film_rgb: *mut f32, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
     pub fn yk_multi_film_clear(m: *mut yk_multi, film: *mut yk_multi_film) -> yk_status;
+    pub fn yk_multi_interrupt(m: *mut yk_multi) -> yk_status;
     pub fn yk_multi_sync(m: *mut yk_multi) -> yk_status;
     pub fn yk_dist_unique_id(id: *mut u8) -> yk_status;
     pub fn yk_dist_create(ctx: *mut yk_context, id: *const u8, rank: u32, world: u32, out: *mut *mut yk_dist) -> yk_status;

@@ -198,6 +198,17 @@ def test_one_shot_predicate_stops_every_rank(ctx, yk, G):
     # the next frame on the same object is unaffected
     got, st = m.render_film(msc, cam, sampler, integ, film)
     assert st.rays == st_full.rays and np.array_equal(_bits(got), _bits(want))
+    # yk_multi_interrupt from another thread while a frame renders: every rank's call comes back cancelled (or the frame had
+    # already finished); the frame after it is whole again
+    timer = threading.Timer(0.002, m.interrupt)
+    timer.start()
+    try:
+        m.render_film(msc, cam, sampler, integ, film)
+    except yk.YukiError as err:
+        assert err.status == 7
+    timer.join()
+    got, st = m.render_film(msc, cam, sampler, integ, film)
+    assert st.rays == st_full.rays and np.array_equal(_bits(got), _bits(want))
     film.close()
     msc.close()
     m.close()

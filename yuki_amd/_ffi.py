@@ -127,6 +127,7 @@ SYMBOLS = {
     "yk_multi_deal": (C.c_size_t, [C.c_uint16, C.c_uint16, C.c_uint16, C.c_uint32, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_uint64)]),
     "yk_multi_accumulate_film": (C.c_int, [vp, vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), vp, C.c_uint32, C.c_uint32, vp, C.POINTER(RenderStats), vp, vp]),
     "yk_multi_film_clear": (C.c_int, [vp, vp]),
+    "yk_multi_interrupt": (C.c_int, [vp]),
     "yk_context_interrupt": (C.c_int, [vp]),
     "yk_multi_destroy": (None, [vp]),
     "yk_multi_device_count": (C.c_uint32, [vp]),

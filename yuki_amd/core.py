@@ -379,6 +379,10 @@ class Multi:
     def clear_film(self, film):
         _mcheck(lib().yk_multi_film_clear(self.h, film.h), self.h)
 
+    def interrupt(self):
+        """yk_multi_interrupt: stop the frame in flight on every rank (any thread)."""
+        check(lib().yk_multi_interrupt(self.h))
+
     def sync(self):
         _mcheck(lib().yk_multi_sync(self.h), self.h)
 

@@ -648,6 +648,13 @@ yk_status yk_multi_film_clear(yk_multi* m, yk_multi_film* film) {
     return YK_OK;
 }
 
+// yk_context_interrupt for every rank: takes no lock (a render call holds it for its whole duration) and makes no HIP call
+yk_status yk_multi_interrupt(yk_multi* m) {
+    if (!m) return YK_ERR_INVALID_ARGUMENT;
+    for (yk_context* c : m->ctx) (void)yk_context_interrupt(c);
+    return YK_OK;
+}
+
 yk_status yk_multi_sync(yk_multi* m) {
     if (!m) return YK_ERR_INVALID_ARGUMENT;
     std::lock_guard<std::mutex> l(m->mu);
