@@ -121,6 +121,7 @@ class _Accum:
         self.background = (F(0), F(0), F(0))
         self.nv = 0
         self.any_n = self.any_uv = False
+        self.pending = []  # pbrt: the shapes in file order, added after the parse
 
     def add_mesh(self, xf, idx, pts, nrm, uv, material):
         """Mesh::new (shapes/mesh.rs:20-43) + one Triangle per index triple."""
@@ -531,6 +532,8 @@ def load_pbrt(path, split_method=abi.SPLIT_SAH, max_shapes_in_node=1):
         cam=dict(position=(F(0),) * 3, target=(F(0),) * 3, up=(F(0), F(1), F(0)), fov=F(0)), res=[640, 480],
     )
     _pbrt_file(path, acc, st)
+    for job in acc.pending:
+        job()
     if not acc.order:
         raise LoadError("pbrt: scene has no shapes")
     res = tuple(st["res"])
@@ -724,9 +727,11 @@ def _pbrt_file(path, acc, st):
             elif d == "Shape":
                 ty = want("str")
                 ps = param_set()
+                # parse_shapes (pbrt/mod.rs:624-700): shapes join the scene in file order AFTER the parse ("collect meshes", :807-822);
+                # plymesh files are read between the two (:786-800), so a parse error further down the file comes first
                 if ty == "sphere":
-                    acc.order.append(("s", len(acc.spheres)))
-                    acc.spheres.append(dict(o2w=st["xf"].m.copy(), w2o=st["xf"].mi.copy(), radius=float(ps.one("float", "radius", F(1.0))), material=st["material"]))
+                    sph = dict(o2w=st["xf"].m.copy(), w2o=st["xf"].mi.copy(), radius=float(ps.one("float", "radius", F(1.0))), material=st["material"])
+                    acc.pending.append(lambda sph=sph: (acc.order.append(("s", len(acc.spheres))), acc.spheres.append(sph)))
                 elif ty == "trianglemesh":
                     idx = [i & 0xFFFFFFFF for i in ps.many("int", "indices")]
                     if len(idx) < 3 or len(idx) % 3:
@@ -734,12 +739,15 @@ def _pbrt_file(path, acc, st):
                     P, N, UV = ps.many("point", "P"), ps.many("normal", "N"), ps.many("uv", "uv")
                     if max(idx) >= len(P) or (N and len(N) != len(P)) or (UV and len(UV) != len(P)):
                         raise LoadError("trianglemesh: inconsistent counts")  # reference: index panic
-                    acc.add_mesh(st["xf"], idx, P, N, UV, st["material"])
+                    acc.pending.append(lambda xf=st["xf"], idx=idx, P=P, N=N, UV=UV, m=st["material"]: acc.add_mesh(xf, idx, P, N, UV, m))
                 elif ty == "plymesh":
                     fn = ps.one("string", "filename", "")
                     if not fn:
                         raise LoadError("Empty PLY filename")
-                    _ply_mesh(acc, os.path.join(parent, fn), st["xf"], st["material"])
+                    ply_path = os.path.join(parent, fn)
+                    if not os.path.isfile(ply_path):  # canonicalize() fails where the file is named (:689-699)
+                        raise LoadError(f"Could not open '{ply_path}'")
+                    acc.pending.append(lambda pp=ply_path, xf=st["xf"], m=st["material"]: _ply_mesh(acc, pp, xf, m))
             elif d == "Texture":
                 name, tt, cls = want("str"), want("str"), want("str")
                 ps = param_set()

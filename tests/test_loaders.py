@@ -366,7 +366,7 @@ def test_cfg3_pbrt_file_loads_to_the_generators_arrays(cfg3_pbrt, cfg3_scene, cf
     assert_same_scene(serial, got)
 
 
-def test_pbrt_parse_error_after_a_broken_ply_wins(tmp_path):
+def test_pbrt_parse_error_after_a_broken_ply_wins(tmp_path, ol):
     """The reference reads `plymesh` files AFTER the parse (pbrt/mod.rs:786-800), so an unknown directive further down the file is
     what the load reports; a missing file ends the load where it is named (canonicalize(), :689-699)."""
     (tmp_path / "bad.ply").write_bytes(b"ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nend_header\n0\n")
@@ -375,6 +375,9 @@ def test_pbrt_parse_error_after_a_broken_ply_wins(tmp_path):
     with pytest.raises(YukiError) as e:
         loaders.load_pbrt(str(p))
     assert "UnimplementedToken" in str(e.value) or "ObjectBegin" in str(e.value)
+    with pytest.raises(ol.LoadError) as oe:  # the independent loader orders its errors the same way
+        ol.load_pbrt(str(p))
+    assert "PLY" not in str(oe.value)
     p.write_text('WorldBegin\nShape "plymesh" "string filename" "bad.ply"\nWorldEnd\n')
     with pytest.raises(YukiError) as e:
         loaders.load_pbrt(str(p))
