@@ -207,10 +207,12 @@ typedef struct yk_scene yk_scene;
  * When is it polled:
  *   - before every batch is enqueued (all calls);
  *   - in a SYNCHRONOUS call — one that returns pixels to the host or is given `stats` — about every
- *     100 us while the GPU works.  On a non-zero answer a word in pinned host memory is set that the
- *     persistent traversal kernels read whenever they claim work and k_shade once per window of
- *     2048 vertices; they stop, every kernel still enqueued finds its queue empty, and the call
- *     returns after the drain (a few ms).  The next render on the context is unaffected.
+ *     100 us while the GPU works.  On a non-zero answer a word in pinned host memory is set; one
+ *     wave of every running traversal launch reads it whenever it claims work, raises a word in
+ *     device memory and poisons the launch's queue head, so no wave claims again; every kernel (every
+ *     block of the grid-stride ones) reads the device word when it starts and finds its queue
+ *     empty; a job of many batches is enqueued two batches at a time.  The call returns after the
+ *     drain (~5 ms into a 1.5-s job).  The next render on the context is unaffected.
  *   - an ASYNCHRONOUS submission (device output, stats == NULL) has returned before the GPU
  *     started: the caller interrupts it with yk_context_interrupt from any thread.
  * The predicate is called from the thread that made the call, never concurrently. */

@@ -224,7 +224,7 @@ void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* s
 }
 
 // ------------------------------------------------------------------ interruption (yk_device.h, CancelRef)
-// Raise the host's word: the persistent kernels see it at their next claim, k_shade at its next window, and they raise the
+// Raise the host's word: every traversal launch's relay wave sees it at its next claim (yk_device.h, CancelRef) and raises the
 // device word that every later launch reads when it starts.
 static void raise_cancel(yk_context* ctx, bool from_render_thread = true) {
     if (!ctx->cancel_host) return;
