@@ -90,6 +90,8 @@ def lib():
         f = getattr(L, "orc_" + fn)
         f.argtypes = [C.c_float]
         f.restype = C.c_float
+    L.orc_libm_array.argtypes = [C.c_int, C.c_size_t, vp, vp, vp]
+    L.orc_libm_array.restype = None
     L.orc_atan2f.argtypes = [C.c_float, C.c_float]
     L.orc_atan2f.restype = C.c_float
     L.orc_mat4_inverse_f32.argtypes = [vp, vp]
@@ -274,6 +276,15 @@ def detile(tiles, rgb, res):
         film[t["y0"] : t["y1"], t["x0"] : t["x1"]] = rgb[off : off + w * h].reshape(h, w, 3)
         off += w * h
     return film
+
+
+def libm_array(fn, x, y=None):
+    """olibm.h over an array: fn 0 sin, 1 cos, 2 tan, 3 log, 4 acos, 5 atan2(x, y)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    yy = None if y is None else np.ascontiguousarray(y, dtype=np.float32)
+    out = np.zeros_like(x)
+    lib().orc_libm_array(fn, x.size, _p(x), _p(yy), _p(out))
+    return out
 
 
 def texture_eval(tex, uv):

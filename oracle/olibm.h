@@ -1,26 +1,34 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.
 //
-// Deterministic single-precision transcendental functions.
+// Single-precision transcendental functions: the platform libm of the reference, restated.
 //
-// The reference calls Rust's f32::{sin,cos,tan,ln,atan2,acos}, which lower to
-// whatever libm the platform links (glibc, musl, MSVCRT ...): their results are
-// NOT pinned by the reference ("parity unpinned").  A
-// path tracer's branches (hemisphere tests, Russian roulette) amplify a 1-ulp
-// difference into a different path, so the oracle and the HIP kernels must use
-// the *same* function.  Both therefore implement this fixed recipe: evaluate in
-// binary64 with the classic fdlibm minimax kernels using only +,-,*,/ and sqrt
-// (all correctly rounded on the host and on gfx950), then round once to
-// binary32.  The result is within 0.5 ulp + 2^-29 of the true value, i.e. a
-// legitimate libm; tests/test_oracle_libm.py bounds the distance to glibc.
+// The reference calls Rust's f32::{sin,cos,tan,ln,atan2,acos}, which lower to whatever libm
+// the platform links; the reference itself does not pin their results.
+// A path tracer's branches (hemisphere tests, Russian roulette) amplify a 1-ulp difference
+// into a different path, so the oracle and the HIP kernels must use the *same* function —
+// and to be the reference's image rather than "an" image it has to be the function the
+// reference calls.  On x86-64 Linux that is glibc; namespace glibc below restates glibc
+// 2.35's sinf, cosf, tanf, logf, acosf, atanf and atan2f operation by operation (published
+// sources: sysdeps/ieee754/flt-32/{s_sinf,s_cosf,s_tanf,k_tanf,e_logf,e_acosf,s_atanf,
+// e_atan2f}.c, sincosf.h; order and fusing read off the instructions of libm.so.6's x86-64
+// build, FMA variants where glibc dispatches to them).  glibc is not under /root/reference
+// — it is the reference's platform dependency — so the pin is the platform's own binary:
+// tools/micro/glibc_libm_check.cpp compares every function with it for ALL 2^32 arguments
+// (atan2f: every argument against 24 special partners + 2^32 random pairs); result in
+// profiles/r03_glibc_libm_check.txt: identical, NaNs as a class.  tests/test_oracle_libm.py
+// repeats a strided subset on every run.  On another libm (musl, macOS, a glibc before
+// 2.28) the reference's own images differ from these in the last bits of a few samples —
+// tools/libm_sensitivity.py measures by how much.
 //
-// No FMA anywhere: compile with -ffp-contract=off.
+// No implicit FMA anywhere: compile with -ffp-contract=off; the fused operations of glibc's
+// FMA builds are explicit std::fma calls.
 //
 // Build flavour -DORC_HOST_LIBM (liboracle_hostlibm.so, tools/libm_sensitivity.py): the six
-// functions call the platform's sinf / cosf / tanf / logf / atan2f / acosf instead — on
-// x86-64 Linux with glibc that is what Rust's f32::{sin,cos,tan,ln,atan2,acos} resolve to
+// functions call the platform's sinf / cosf / tanf / logf / atan2f / acosf instead
 // (call sites: sampling/mod.rs:62-87, trowbridge_reitz.rs:23-30,60-74, camera.rs:52-102,
-// sphere.rs:38-119).  It measures how far the fixed recipe moves an IMAGE from the one a
-// glibc build of the reference would produce; it is never the parity oracle.
+// sphere.rs:38-119).  On glibc 2.35 it must render the oracle's images bit for bit (asserted
+// in tests/test_oracle_sensitivity.py); on another platform it measures that platform's
+// distance.  It is never the parity oracle.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -29,198 +37,398 @@
 namespace orc {
 namespace lm {
 
-inline double k_sin(double r) {
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
-                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    double z = r * r;
-    double p = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-    return r + (r * z) * (S1 + z * p);
+// ---------------------------------------------------------------------------------------------------------------
+// sinf / cosf (s_sinf.c, s_cosf.c, sincosf.h — the single-precision routines of ARM's optimized-routines that glibc ships since 2.28).
+// x86-64 glibc selects its FMA build at run time (`__sinf_fma`, ifunc) on every CPU with FMA3 + AVX2; which `a + b*c` are fused below
+// is that build's: the polynomial helpers compile to exactly the fused multiply-adds the source's expressions suggest, the reduction
+// `x - n*hpi` is one vfnmadd.  Constants: __sincosf_table, __inv_pio4.
+namespace glibc {
+
+// { sign[4], hpi_inv * 2^24, hpi, c0, c1, s1, c2, s2, c3, s3, c4 }; the second table serves the quadrants whose result is negated
+static const double sincosf_table[2][14] = {
+    {1.0, -1.0, -1.0, 1.0, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0, -0x1.ffffffd0c621cp-2, -0x1.555545995a603p-3, 0x1.55553e1068f19p-5,
+     0x1.1107605230bc4p-7, -0x1.6c087e89a359dp-10, -0x1.994eb3774cf24p-13, 0x1.99343027bf8c3p-16},
+    {1.0, -1.0, -1.0, 1.0, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.555545995a603p-3, -0x1.55553e1068f19p-5,
+     0x1.1107605230bc4p-7, 0x1.6c087e89a359dp-10, -0x1.994eb3774cf24p-13, -0x1.99343027bf8c3p-16}};
+// 4/pi as a bit string, 32 bits at every 8-bit offset (reduce_large)
+static const uint32_t inv_pio4[24] = {0xa2,       0xa2f9,     0xa2f983,   0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529,
+                                      0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0,
+                                      0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041};
+
+// sinf_poly, even quadrant: x + x^3 (s1 + x^2 (s2 + x^2 s3)) in this association; xs = x * sign
+inline float poly_sin(double xs, double x2, const double* p) {
+    double s1 = std::fma(x2, p[12], p[10]);
+    double x3 = x2 * xs;
+    double x7 = x2 * x3;
+    double s = std::fma(x3, p[8], xs);
+    return (float)std::fma(s1, x7, s);
+}
+// sinf_poly, odd quadrant: c0 + c1 x^2 + c2 x^4 + x^6 (c3 + c4 x^2)
+inline float poly_cos(double x2, const double* p) {
+    double x4 = x2 * x2;
+    double c1 = std::fma(x2, p[7], p[6]);
+    double c2 = std::fma(x2, p[13], p[11]);
+    double x6 = x2 * x4;
+    double c = std::fma(x4, p[9], c1);
+    return (float)std::fma(c2, x6, c);
+}
+// reduce_fast: |x| < 120; n = round(x / (pi/2)) through the 2^24-scaled product, x - n * pi/2 in one fused step
+inline double reduce_fast(double x, int& n) {
+    double r = x * sincosf_table[0][4];
+    n = ((int32_t)r + 0x800000) >> 24;
+    return std::fma(-(double)n, sincosf_table[0][5], x);
+}
+// reduce_large: 120 <= |x| < inf, the argument's 24 mantissa bits times 96 bits of 4/pi
+inline double reduce_large(uint32_t xi, int& n) {
+    const uint32_t* arr = &inv_pio4[(xi >> 26) & 15];
+    int shift = (int)((xi >> 23) & 7);
+    xi = (xi & 0xffffff) | 0x800000;
+    xi <<= shift;
+    uint64_t res0 = (uint64_t)(uint32_t)(xi * arr[0]);
+    uint64_t res1 = (uint64_t)xi * arr[4];
+    uint64_t res2 = (uint64_t)xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    uint64_t nn = (res0 + (1ULL << 61)) >> 62;
+    res0 -= nn << 62;
+    n = (int)nn;
+    return (double)(int64_t)res0 * 0x1.921FB54442D18p-62;
+}
+inline uint32_t abstop12(float y) {
+    uint32_t b;
+    std::memcpy(&b, &y, 4);
+    return (b >> 20) & 0x7ff;
 }
 
-inline double k_cos(double r) {
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
-                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double z = r * r;
-    double p = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
-    return (1.0 - 0.5 * z) + z * p;
+inline float sinf(float y) {
+    double x = (double)y;
+    const uint32_t top = abstop12(y);
+    const double* p = sincosf_table[0];
+    int n;
+    if (top < 0x3f4) {  // |y| < pi/4
+        double x2 = x * x;
+        if (top < 0x398) return y;  // |y| < 2^-12
+        return poly_sin(x, x2, p);
+    }
+    uint32_t xi;
+    std::memcpy(&xi, &y, 4);
+    int sign = 0;
+    if (top < 0x42f) {  // |y| < 120
+        x = reduce_fast(x, n);
+    } else if (top < 0x7f8) {
+        sign = (int)(xi >> 31);
+        x = reduce_large(xi, n);
+    } else {
+        return y - y;  // inf, NaN: __math_invalidf
+    }
+    double s = p[(n + sign) & 3];
+    if ((n + sign) & 2) p = sincosf_table[1];
+    return (n & 1) ? poly_cos(x * x, p) : poly_sin(x * s, x * x, p);
 }
 
-// r = x - n*(pi/2), n = nearest integer; three-part Cody-Waite in binary64.
-// Accurate for |x| up to ~1e6 (the hot path feeds |x| <= 2*pi).
-inline double reduce_pio2(double x, int64_t& n) {
-    const double INV_PIO2 = 6.36619772367581382433e-01;
-    const double P1 = 1.57079632673412561417e+00;   // first 33 bits of pi/2
-    const double P2 = 6.07710050630396597660e-11;   // next 33 bits
-    const double P3 = 2.02226624879595063154e-21;   // remainder
-    double fn = std::floor(x * INV_PIO2 + 0.5);
-    n = (int64_t)fn;
-    double r = x - fn * P1;
-    r = r - fn * P2;
-    r = r - fn * P3;
-    return r;
+inline float cosf(float y) {
+    double x = (double)y;
+    const uint32_t top = abstop12(y);
+    const double* p = sincosf_table[0];
+    int n;
+    if (top < 0x3f4) {
+        double x2 = x * x;
+        if (top < 0x398) return 1.0f;
+        return poly_cos(x2, p);
+    }
+    uint32_t xi;
+    std::memcpy(&xi, &y, 4);
+    int sign = 0;
+    if (top < 0x42f) {
+        x = reduce_fast(x, n);
+    } else if (top < 0x7f8) {
+        sign = (int)(xi >> 31);
+        x = reduce_large(xi, n);
+    } else {
+        return y - y;
+    }
+    double s = p[(n + sign) & 3];
+    if ((n + sign) & 2) p = sincosf_table[1];
+    return (n & 1) ? poly_sin(x * s, x * x, p) : poly_cos(x * x, p);  // sinf_poly(.., n ^ 1)
 }
+
+
+inline float from_bits(uint32_t b) {
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+inline uint32_t to_bits(float f) {
+    uint32_t b;
+    std::memcpy(&b, &f, 4);
+    return b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// logf (sysdeps/ieee754/flt-32/e_logf.c + e_logf_data.c, the same ARM routine family; x86-64 dispatches to `__logf_fma`): a 16-entry
+// table of 1/c and log(c), a cubic in binary64, one rounding to binary32.  Fused exactly where the FMA build fuses:
+// r = fma(z, invc, -1), y0 = fma(k, ln2, logc), the cubic as two fma, the sum as one.
+static const double logf_tab[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2}, {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},
+    {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3}, {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4}, {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5},
+    {0x1p+0, 0x0p+0},                              {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+    {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},   {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},
+    {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+inline float logf(float xf) {
+    uint32_t ix = to_bits(xf);
+    if (ix == 0x3f800000u) return 0.0f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {  // zero, subnormal, negative, inf, NaN
+        if (ix * 2u == 0u) return -1.0f / 0.0f;
+        if (ix == 0x7f800000u) return xf;
+        if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return (xf - xf) / 0.0f;
+        ix = to_bits(xf * 0x1p23f) - (23u << 23);
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const int k = (int32_t)tmp >> 23;
+    const double z = (double)from_bits(ix - (tmp & 0xff800000u));
+    const double r = std::fma(z, logf_tab[i][0], -1.0);
+    const double y0 = std::fma((double)k, 0x1.62e42fefa39efp-1, logf_tab[i][1]);
+    const double r2 = r * r;
+    double y = std::fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
+    y = std::fma(-0x1.00ea348b88334p-2, r2, y);
+    return (float)std::fma(y, r2, y0 + r);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// acosf, atanf, atan2f, tanf: in glibc 2.35 these are still the binary32 fdlibm routines (e_acosf.c, s_atanf.c, e_atan2f.c,
+// k_tanf.c; built for baseline x86-64, so no operation is fused), tanf with 2.35's argument reduction (s_tanf.c: the reduce_fast /
+// reduce_large of sincosf.h, unfused here, the reduced argument split into a binary32 head and tail).  Plain binary32 + - * / sqrt
+// in the order the instructions of libm.so.6 perform them.
+inline float acosf(float x) {
+    const float pi = from_bits(0x40490fdau), pio2_hi = from_bits(0x3fc90fdau), pio2_lo = from_bits(0x33a22168u);
+    const float p0 = from_bits(0x3e2aaaabu), p1 = from_bits(0xbea6b090u), p2 = from_bits(0x3e4e0aa8u), p3 = from_bits(0xbd241146u),
+                p4 = from_bits(0x3a4f7f04u), p5 = from_bits(0x3811ef08u);
+    const float q1 = from_bits(0xc019d139u), q2 = from_bits(0x4001572du), q3 = from_bits(0xbf303361u), q4 = from_bits(0x3d9dc62eu);
+    const int32_t hx = (int32_t)to_bits(x), ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
+    if (ix > 0x3f800000) return (x - x) / (x - x);
+    if (ix < 0x3f000000) {  // |x| < 0.5
+        if (ix <= 0x32800000) return pio2_hi + pio2_lo;
+        const float z = x * x;
+        const float p = z * (p0 + z * (p1 + z * (p2 + z * (p3 + z * (p4 + z * p5)))));
+        const float q = 1.0f + z * (q1 + z * (q2 + z * (q3 + z * q4)));
+        const float r = p / q;
+        return pio2_hi - (x - (pio2_lo - r * x));
+    }
+    if (hx < 0) {  // x < -0.5
+        const float z = (1.0f + x) * 0.5f;
+        const float p = z * (p0 + z * (p1 + z * (p2 + z * (p3 + z * (p4 + z * p5)))));
+        const float q = 1.0f + z * (q1 + z * (q2 + z * (q3 + z * q4)));
+        const float s = std::sqrt(z);
+        const float r = p / q;
+        const float w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    }
+    const float z = (1.0f - x) * 0.5f;  // x > 0.5
+    const float s = std::sqrt(z);
+    const float df = from_bits(to_bits(s) & 0xfffff000u);
+    const float c = (z - df * df) / (s + df);
+    const float p = z * (p0 + z * (p1 + z * (p2 + z * (p3 + z * (p4 + z * p5)))));
+    const float q = 1.0f + z * (q1 + z * (q2 + z * (q3 + z * q4)));
+    const float r = p / q;
+    const float w = r * s + c;
+    return 2.0f * (df + w);
+}
+
+inline float atanf(float x) {
+    static const uint32_t hi_bits[4] = {0x3eed6338u, 0x3f490fdau, 0x3f7b985eu, 0x3fc90fdau};
+    static const uint32_t lo_bits[4] = {0x31ac3769u, 0x33222168u, 0x33140fb4u, 0x33a22168u};
+    const float a0 = from_bits(0x3eaaaaabu), a1 = from_bits(0xbe4ccccdu), a2 = from_bits(0x3e124925u), a3 = from_bits(0xbde38e38u),
+                a4 = from_bits(0x3dba2e6eu), a5 = from_bits(0xbd9d8795u), a6 = from_bits(0x3d886b35u), a7 = from_bits(0xbd6ef16bu),
+                a8 = from_bits(0x3d4bda59u), a9 = from_bits(0xbd15a221u), a10 = from_bits(0x3c8569d7u);
+    const int32_t hx = (int32_t)to_bits(x), ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) {  // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;
+        return hx > 0 ? from_bits(hi_bits[3]) + from_bits(lo_bits[3]) : -from_bits(hi_bits[3]) - from_bits(lo_bits[3]);
+    }
+    if (ix < 0x3ee00000) {  // |x| < 7/16
+        if (ix < 0x31000000) return x;
+        id = -1;
+    } else {
+        x = std::fabs(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) {
+                id = 0;
+                x = (2.0f * x - 1.0f) / (2.0f + x);
+            } else {
+                id = 1;
+                x = (x - 1.0f) / (x + 1.0f);
+            }
+        } else if (ix < 0x401c0000) {
+            id = 2;
+            x = (x - 1.5f) / (1.0f + 1.5f * x);
+        } else {
+            id = 3;
+            x = -1.0f / x;
+        }
+    }
+    const float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
+    const float s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = from_bits(hi_bits[id]) - ((x * (s1 + s2) - from_bits(lo_bits[id])) - x);
+    return hx < 0 ? -r : r;
+}
+
+inline float atan2f(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = from_bits(0x3f490fdbu), pi_o_2 = from_bits(0x3fc90fdbu), pi = from_bits(0x40490fdbu),
+                pi_lo = from_bits(0xb3bbbd2eu);
+    const int32_t hx = (int32_t)to_bits(x), hy = (int32_t)to_bits(y), ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return atanf(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);  // 2 * sign(x) + sign(y)
+    if (iy == 0) {
+        if (m < 2) return y;
+        return m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) {
+            switch (m) {
+                case 0: return pi_o_4 + tiny;
+                case 1: return -pi_o_4 - tiny;
+                case 2: return 3.0f * pi_o_4 + tiny;
+                default: return -3.0f * pi_o_4 - tiny;
+            }
+        }
+        switch (m) {
+            case 0: return 0.0f;
+            case 1: return -0.0f;
+            case 2: return pi + tiny;
+            default: return -pi - tiny;
+        }
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60)
+        z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60)
+        z = 0.0f;
+    else
+        z = atanf(std::fabs(y / x));
+    switch (m) {
+        case 0: return z;
+        case 1: return from_bits(to_bits(z) ^ 0x80000000u);
+        case 2: return pi - (z - pi_lo);
+        default: return (z - pi_lo) - pi;
+    }
+}
+
+// __kernel_tanf: tan(x + y) for |x + y| <= pi/4 (iy = 1) or -1 / tan (iy = -1)
+inline float kernel_tanf(float x, float y, int iy) {
+    const float pio4 = from_bits(0x3f490fdau), pio4lo = from_bits(0x33222168u);
+    const float t0 = from_bits(0x3eaaaaabu), t1 = from_bits(0x3e088889u), t2 = from_bits(0x3d5d0dd1u), t3 = from_bits(0x3cb327a4u),
+                t4 = from_bits(0x3c11371fu), t5 = from_bits(0x3b6b6916u), t6 = from_bits(0x3abede48u), t7 = from_bits(0x3a1a26c8u),
+                t8 = from_bits(0x398137b9u), t9 = from_bits(0x38a3f445u), t10 = from_bits(0x3895c07au), t11 = from_bits(0xb79bae5fu),
+                t12 = from_bits(0x37d95384u);
+    const int32_t hx = (int32_t)to_bits(x), ix = hx & 0x7fffffff;
+    if (ix < 0x39000000) {  // |x| < 2^-13: (int)x == 0
+        if ((ix | (iy + 1)) == 0) return 1.0f / std::fabs(x);
+        return iy == 1 ? x : -1.0f / x;
+    }
+    if (ix >= 0x3f2ca140) {  // |x| >= 0.6744
+        if (hx < 0) {
+            x = -x;
+            y = -y;
+        }
+        const float z = pio4 - x;
+        const float w = pio4lo - y;
+        x = z + w;
+        y = 0.0f;
+        if (std::fabs(x) < 0x1p-13f) return (float)((1 - ((hx >> 30) & 2)) * iy) * (1.0f - (float)(2 * iy) * x);
+    }
+    const float z = x * x;
+    float w = z * z;
+    float r = t1 + w * (t3 + w * (t5 + w * (t7 + w * (t9 + w * t11))));
+    float v = z * (t2 + w * (t4 + w * (t6 + w * (t8 + w * (t10 + w * t12)))));
+    float s = z * x;
+    r = y + z * (s * (r + v) + y);
+    r += t0 * s;
+    w = x + r;
+    if (ix >= 0x3f2ca140) {
+        v = (float)iy;
+        return (float)(1 - ((hx >> 30) & 2)) * (v - 2.0f * (x - (w * w / (w + v) - r)));
+    }
+    if (iy == 1) return w;
+    const float zz = from_bits(to_bits(w) & 0xfffff000u);  // -1 / (x + r), accurately
+    v = r - (zz - x);
+    const float a = -1.0f / w;
+    const float t = from_bits(to_bits(a) & 0xfffff000u);
+    s = 1.0f + t * zz;
+    return t + a * (s + t * v);
+}
+
+inline float tanf(float x) {
+    const int32_t hx = (int32_t)to_bits(x), ix = hx & 0x7fffffff;
+    if (ix <= 0x3f490fda) return kernel_tanf(x, 0.0f, 1);  // |x| <= pi/4
+    if (ix >= 0x7f800000) return x - x;
+    double dx = (double)x;
+    int n;
+    if (abstop12(x) < 0x42f) {  // |x| < 120: reduce_fast, NOT fused in this function
+        const double r = dx * sincosf_table[0][4];
+        n = ((int32_t)r + 0x800000) >> 24;
+        dx = dx - (double)n * sincosf_table[0][5];
+    } else {
+        dx = reduce_large((uint32_t)hx, n);
+        if (hx < 0) dx = -dx;
+    }
+    const float y0 = (float)dx;
+    const float y1 = (float)(dx - (double)y0);
+    return kernel_tanf(y0, y1, 1 - ((n & 1) << 1));
+}
+
+}  // namespace glibc
 
 inline float sinf_(float xf) {
-#ifdef ORC_HOST_LIBM
+#if defined(ORC_HOST_LIBM) && (!defined(ORC_HOST_LIBM_ONLY) || ((ORC_HOST_LIBM_ONLY) & 1))
     return ::sinf(xf);  // sensitivity flavour: the platform libm, what Rust's f32 methods call on Linux
 #endif
-    double x = (double)xf;
-    if (!(std::fabs(x) < 1.0e300)) return xf - xf;  // inf/NaN -> NaN
-    int64_t n;
-    double r = reduce_pio2(x, n);
-    double v;
-    switch (n & 3) {
-        case 0: v = k_sin(r); break;
-        case 1: v = k_cos(r); break;
-        case 2: v = -k_sin(r); break;
-        default: v = -k_cos(r); break;
-    }
-    return (float)v;
+    return glibc::sinf(xf);  // glibc's algorithm restated: equal to the line above for all 2^32 arguments on glibc 2.35 / x86-64 with FMA
 }
 
 inline float cosf_(float xf) {
-#ifdef ORC_HOST_LIBM
-    return ::cosf(xf);  // sensitivity flavour: the platform libm, what Rust's f32 methods call on Linux
+#if defined(ORC_HOST_LIBM) && (!defined(ORC_HOST_LIBM_ONLY) || ((ORC_HOST_LIBM_ONLY) & 1))
+    return ::cosf(xf);
 #endif
-    double x = (double)xf;
-    if (!(std::fabs(x) < 1.0e300)) return xf - xf;
-    int64_t n;
-    double r = reduce_pio2(x, n);
-    double v;
-    switch (n & 3) {
-        case 0: v = k_cos(r); break;
-        case 1: v = -k_sin(r); break;
-        case 2: v = -k_cos(r); break;
-        default: v = k_sin(r); break;
-    }
-    return (float)v;
+    return glibc::cosf(xf);
 }
 
 inline float tanf_(float xf) {
-#ifdef ORC_HOST_LIBM
-    return ::tanf(xf);  // sensitivity flavour: the platform libm, what Rust's f32 methods call on Linux
+#if defined(ORC_HOST_LIBM) && (!defined(ORC_HOST_LIBM_ONLY) || ((ORC_HOST_LIBM_ONLY) & 2))
+    return ::tanf(xf);
 #endif
-    double x = (double)xf;
-    if (!(std::fabs(x) < 1.0e300)) return xf - xf;
-    int64_t n;
-    double r = reduce_pio2(x, n);
-    double s = k_sin(r), c = k_cos(r);
-    double v = (n & 1) ? -(c / s) : (s / c);
-    return (float)v;
+    return glibc::tanf(xf);
 }
 
-// natural log of a positive finite binary32 value, evaluated in binary64
 inline float logf_(float xf) {
-#ifdef ORC_HOST_LIBM
-    return ::logf(xf);  // sensitivity flavour: the platform libm, what Rust's f32 methods call on Linux
+#if defined(ORC_HOST_LIBM) && (!defined(ORC_HOST_LIBM_ONLY) || ((ORC_HOST_LIBM_ONLY) & 4))
+    return ::logf(xf);
 #endif
-    if (xf != xf) return xf;
-    if (xf < 0.0f) return (xf - xf) / 0.0f;                   // NaN
-    if (xf == 0.0f) return -1.0f / 0.0f;                      // -inf (Rust ln(0) = -inf)
-    if (xf > 3.0e38f && xf + xf == xf) return xf;             // +inf
-    const double LN2 = 6.93147180559945286227e-01;
-    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
-                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                 Lg7 = 1.479819860511658591e-01;
-    double x = (double)xf;  // exact; subnormal floats become normal doubles
-    uint64_t bits;
-    std::memcpy(&bits, &x, 8);
-    int64_t e = (int64_t)((bits >> 52) & 0x7ff) - 1023;
-    bits = (bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
-    double m;
-    std::memcpy(&m, &bits, 8);  // m in [1,2)
-    if (m > 1.41421356237309514547) {
-        m = m * 0.5;
-        e += 1;
-    }
-    double f = m - 1.0;
-    double s = f / (2.0 + f);
-    double z = s * s;
-    double R = z * (Lg1 + z * (Lg2 + z * (Lg3 + z * (Lg4 + z * (Lg5 + z * (Lg6 + z * Lg7))))));
-    double lg = 2.0 * s + s * R;
-    return (float)((double)e * LN2 + lg);
-}
-
-// atan on [0, inf) in binary64, fdlibm breakpoints
-inline double k_atan_pos(double x) {
-    const double atanhi[4] = {4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01,
-                              1.57079632679489655800e+00};
-    const double atanlo[4] = {2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17,
-                              6.12323399573676603587e-17};
-    const double aT[11] = {3.33333333333329318027e-01,  -1.99999999998764832476e-01, 1.42857142725034663711e-01,
-                           -1.11111104054623557880e-01, 9.09088713343650656196e-02,  -7.69187620504482999495e-02,
-                           6.66107313738753120669e-02,  -5.83357013379057348645e-02, 4.97687799461593236017e-02,
-                           -3.65315727442169155270e-02, 1.62858201153657823623e-02};
-    int id;
-    if (x < 0.4375) {
-        id = -1;
-    } else if (x < 1.1875) {
-        if (x < 0.6875) {
-            id = 0;
-            x = (2.0 * x - 1.0) / (2.0 + x);
-        } else {
-            id = 1;
-            x = (x - 1.0) / (x + 1.0);
-        }
-    } else {
-        if (x < 2.4375) {
-            id = 2;
-            x = (x - 1.5) / (1.0 + 1.5 * x);
-        } else {
-            id = 3;
-            x = -1.0 / x;
-        }
-    }
-    double z = x * x;
-    double w = z * z;
-    double s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
-    double s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
-    if (id < 0) return x - x * (s1 + s2);
-    return atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return glibc::logf(xf);
 }
 
 inline float atan2f_(float yf, float xf) {
-#ifdef ORC_HOST_LIBM
-    return ::atan2f(yf, xf);  // sensitivity flavour: the platform libm, what Rust's f32 methods call on Linux
+#if defined(ORC_HOST_LIBM) && (!defined(ORC_HOST_LIBM_ONLY) || ((ORC_HOST_LIBM_ONLY) & 8))
+    return ::atan2f(yf, xf);
 #endif
-    const double PI = 3.14159265358979311600e+00, PIO2 = 1.57079632679489655800e+00;
-    if (xf != xf || yf != yf) return xf + yf;
-    double y = (double)yf, x = (double)xf;
-    if (y == 0.0) {
-        bool xneg = std::signbit(xf);
-        double v = xneg ? PI : 0.0;
-        return (float)(std::signbit(yf) ? -v : v);
-    }
-    if (x == 0.0) return (float)(y > 0.0 ? PIO2 : -PIO2);
-    double ax = std::fabs(x), ay = std::fabs(y);
-    double a;
-    if (ax > 1.0e300 && ay > 1.0e300)
-        a = 7.85398163397448278999e-01;
-    else if (ay > 1.0e300)
-        a = PIO2;
-    else if (ax > 1.0e300)
-        a = 0.0;
-    else
-        a = k_atan_pos(ay / ax);
-    if (x < 0.0) a = PI - a;
-    return (float)(y < 0.0 ? -a : a);
+    return glibc::atan2f(yf, xf);
 }
 
 inline float acosf_(float xf) {
-#ifdef ORC_HOST_LIBM
-    return ::acosf(xf);  // sensitivity flavour: the platform libm, what Rust's f32 methods call on Linux
+#if defined(ORC_HOST_LIBM) && (!defined(ORC_HOST_LIBM_ONLY) || ((ORC_HOST_LIBM_ONLY) & 8))
+    return ::acosf(xf);
 #endif
-    if (xf != xf) return xf;
-    double x = (double)xf;
-    if (x > 1.0 || x < -1.0) return (xf - xf) / (xf - xf);  // NaN
-    // acos(x) = 2*atan2(sqrt(1-x), sqrt(1+x))
-    double a = std::sqrt(1.0 - x), b = std::sqrt(1.0 + x);
-    double t;
-    if (b == 0.0)
-        t = 1.57079632679489655800e+00;
-    else
-        t = k_atan_pos(a / b);
-    return (float)(2.0 * t);
+    return glibc::acosf(xf);
 }
 
 }  // namespace lm

@@ -3,7 +3,7 @@ the CPU oracle on the same scene, camera, sampler seed.
 
 Bar (BASELINE.json north_star): per-pixel radiance RMSE < 1e-4 vs the CPU
 reference.  Because every arithmetic step is restated operation for operation
-(f64 islands, unfused mul/add, shared libm recipe) the GPU result is expected to
+(f64 islands, unfused mul/add, shared libm (glibc restated)) the GPU result is expected to
 be BIT-IDENTICAL to the oracle's; the tests assert that, and the RMSE bound as
 the stated tolerance."""
 import numpy as np

@@ -1,8 +1,48 @@
-"""The oracle's deterministic libm (oracle/olibm.h): how far is it from the
-correctly rounded value and from the host's glibc (what the Rust reference would
-call on Linux)?  Parity for transcendental calls is 'unpinned' by the reference;
-these bounds document the substitution."""
+"""The oracle's libm (oracle/olibm.h) against what the Rust reference calls on Linux, the
+platform's glibc: all six functions restate glibc 2.35's own algorithms (sinf / cosf / logf in
+the FMA variants every x86-64 host with FMA3 dispatches to) and must be bit-equal to them.
+The exhaustive 2^32 comparison is tools/micro/glibc_libm_check.cpp
+(profiles/r03_glibc_libm_check.txt); the strided one here runs in seconds.  Accuracy against
+the correctly rounded value is bounded too, so that a host with another libm (where the
+bit-equality test skips) still checks the functions are what they claim to be."""
+import ctypes
+import ctypes.util
+
 import numpy as np
+import pytest
+
+
+def _host_libm():
+    path = ctypes.util.find_library("m")
+    if path is None:
+        pytest.skip("no libm to compare with")
+    L = ctypes.CDLL(path)
+    for n in ("sinf", "cosf", "tanf", "logf", "acosf"):
+        getattr(L, n).argtypes = [ctypes.c_float]
+        getattr(L, n).restype = ctypes.c_float
+    L.atan2f.argtypes = [ctypes.c_float, ctypes.c_float]
+    L.atan2f.restype = ctypes.c_float
+    return L
+
+
+def _host_has_fma():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return " fma " in line + " "
+    except OSError:
+        pass
+    return False
+
+
+def _glibc_version():
+    try:
+        f = ctypes.CDLL(None).gnu_get_libc_version
+        f.restype = ctypes.c_char_p
+        return tuple(int(v) for v in f().decode().split(".")[:2])
+    except (AttributeError, ValueError):
+        return None
 
 
 def _ulp_diff(a, b):
@@ -13,27 +53,53 @@ def _ulp_diff(a, b):
     return np.abs(ai - bi)
 
 
-def test_libm_is_correctly_rounded_on_samples_and_within_1ulp_of_glibc(oracle):
-    L = oracle.lib()
+def test_libm_accuracy_bounds(oracle):
+    """None of glibc's binary32 functions is correctly rounded; the restatements inherit their error bounds
+    (sinf / cosf / logf below 1 ulp, the fdlibm ones below 1 ulp on these ranges, tanf below 2)."""
     rng = np.random.default_rng(5)
     x = rng.uniform(-7, 7, 20000).astype(np.float32)
-    for name, ref64 in (("orc_sinf", np.sin), ("orc_cosf", np.cos), ("orc_tanf", np.tan)):
-        got = np.array([getattr(L, name)(float(v)) for v in x], dtype=np.float32)
-        cr = ref64(x.astype(np.float64)).astype(np.float32)  # round(f64 libm) = correctly rounded except ~2^-29 of cases
-        assert _ulp_diff(got, cr).max() == 0, name
-    g32 = {"orc_sinf": np.sin, "orc_cosf": np.cos}
-    for name, f in g32.items():
-        got = np.array([getattr(L, name)(float(v)) for v in x], dtype=np.float32)
-        assert _ulp_diff(got, f(x)).max() <= 1, name  # numpy float32 sin/cos
+    x64 = x.astype(np.float64)
+    for fn, ref64, bound in ((0, np.sin, 1), (1, np.cos, 1), (2, np.tan, 2)):
+        assert _ulp_diff(oracle.libm_array(fn, x), ref64(x64).astype(np.float32)).max() <= bound, fn
     p = (np.abs(x) + 1e-6).astype(np.float32)
-    got = np.array([L.orc_logf(float(v)) for v in p], dtype=np.float32)
-    assert _ulp_diff(got, np.log(p.astype(np.float64)).astype(np.float32)).max() == 0
+    assert _ulp_diff(oracle.libm_array(3, p), np.log(p.astype(np.float64)).astype(np.float32)).max() <= 1
     c = rng.uniform(-1, 1, 20000).astype(np.float32)
-    got = np.array([L.orc_acosf(float(v)) for v in c], dtype=np.float32)
-    assert _ulp_diff(got, np.arccos(c.astype(np.float64)).astype(np.float32)).max() == 0
+    assert _ulp_diff(oracle.libm_array(4, c), np.arccos(c.astype(np.float64)).astype(np.float32)).max() <= 1
     y = rng.uniform(-3, 3, 20000).astype(np.float32)
-    got = np.array([L.orc_atan2f(float(a), float(b)) for a, b in zip(y, x)], dtype=np.float32)
-    assert _ulp_diff(got, np.arctan2(y.astype(np.float64), x.astype(np.float64)).astype(np.float32)).max() == 0
+    assert _ulp_diff(oracle.libm_array(5, y, x), np.arctan2(y.astype(np.float64), x64).astype(np.float32)).max() <= 1
+
+
+def _same(a, b):
+    return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+
+
+def test_the_six_functions_are_the_platform_libms_bit_for_bit(oracle):
+    """What `f32::{sin,cos,tan,ln,acos,atan2}` lower to in the reference on Linux (sampling/mod.rs:62-87,
+    trowbridge_reitz.rs:23-30, camera.rs:52-102, sphere.rs:38-119): glibc's functions.  Every 65,521st float
+    (65,548 arguments across all exponents, both signs, NaN / inf / denormals included) plus 100,000 random ones
+    in the range the renderer uses; atan2f on 165,548 pairs."""
+    if not _host_has_fma():
+        pytest.skip("the restatement is of glibc's FMA variants; this host dispatches to others")
+    v = _glibc_version()
+    if v is None or v < (2, 35):
+        pytest.skip("glibc older than 2.35 (tanf's reduction changed there; sinf / cosf / logf in 2.27-2.28)")
+    host = _host_libm()
+    bits = np.arange(0, 1 << 32, 65521, dtype=np.uint64).astype(np.uint32)
+    rng = np.random.default_rng(77)
+    x = np.concatenate([bits.view(np.float32), rng.uniform(-7, 7, 100000).astype(np.float32),
+                        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 3.4e38, 0.785398185, 1.57079637, 1.0, -1.0, 0.5, -0.5], np.float32)])
+    for fn, name in ((0, "sinf"), (1, "cosf"), (2, "tanf"), (3, "logf"), (4, "acosf")):
+        got = oracle.libm_array(fn, x)
+        f = getattr(host, name)
+        want = np.array([f(float(a)) for a in x], dtype=np.float32)
+        same = _same(got, want)
+        assert same.all(), (name, x[~same][:8], got[~same][:8], want[~same][:8])
+    y = np.concatenate([rng.permutation(bits).view(np.float32), rng.uniform(-3, 3, 100000).astype(np.float32),
+                        np.array([0.0, -0.0, 0.0, -0.0, np.inf, -np.inf, np.inf, 1.0, -1.0, 1e-30, 1e30, 0.0, 1.0], np.float32)])
+    got = oracle.libm_array(5, y, x)
+    want = np.array([host.atan2f(float(a), float(b)) for a, b in zip(y, x)], dtype=np.float32)
+    same = _same(got, want)
+    assert same.all(), ("atan2f", y[~same][:8], x[~same][:8], got[~same][:8], want[~same][:8])
 
 
 def test_libm_special_values(oracle):

@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
-"""How far can the oracle's two private choices move an IMAGE?  (CPU only.)
+"""The oracle's platform-dependent choices in image space.  (CPU only.)
 
 The reference leaves two things to its platform: Rust's f32::{sin,cos,tan,ln,atan2,acos} are the
 platform libm (call sites sampling/mod.rs:62-87, trowbridge_reitz.rs:23-30,60-74, camera.rs:52-102,
 sphere.rs:38-119), and `select_nth_unstable_by` (bvh.rs:430) orders equal keys as std's pdqselect
-happens to.  The oracle (and the HIP kernels) fix both: olibm.h's recipe and the select_nth spec.
-This script renders the same tiles with two more oracle builds (oracle/Makefile `flavours`):
+happens to.  The oracle (and the HIP kernels) restate glibc 2.35's functions bit for bit (olibm.h)
+and fix the selection by a spec.  This script renders the same tiles with two more oracle builds
+(oracle/Makefile `flavours`):
 
-  hostlibm   the six functions call glibc's sinf ... — what a Linux build of the reference links
+  hostlibm   the six functions call the platform's sinf ... — what a build of the reference links here
   nth        std::nth_element in place of the select_nth spec — another legitimate selection
 
 and reports, against the default oracle, per-pixel RMSE (the north-star tolerance is 1e-4), the
 largest absolute difference, how many pixels / camera samples differ in any bit and how many
-samples took a different path (their ray count differs is not visible per sample; a sample whose
-radiance moves by more than 1e-3 relative is counted as "another path").
+samples took a different path (a sample whose radiance moves by more than 1e-3 relative is counted
+as "another path").  On glibc >= 2.35 / x86-64 with FMA every hostlibm row must read 0: the
+restatement IS the platform's libm.  On another platform the rows are that platform's distance from
+the Linux images; profiles/r03_libm_sensitivity_f64_recipe.txt keeps the table of the fixed f64
+recipe the oracle used before (1.7e-5 on cfg3, 1.4e-3 on a Cornell tile, all of it sinf / cosf).
 
     python tools/libm_sensitivity.py [--quick] [--out profiles/r03_libm_sensitivity.txt]
 """

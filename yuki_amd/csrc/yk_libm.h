@@ -1,180 +1,375 @@
-// yk_libm.h — the transcendental functions the Path hot path needs, as one fixed
-// recipe that runs identically on the host and on gfx950.
+// yk_libm.h — the transcendental functions the Path hot path needs, bit for bit the
+// functions the reference calls, on the host and on gfx950.
 //
 // The reference calls Rust's f32::{sin,cos,tan,ln,acos,atan2} (call sites:
 // sampling/mod.rs:86, bsdfs/mod.rs:280, trowbridge_reitz.rs:24, camera.rs:64,
-// spot_light.rs:33-34, sphere.rs:90,102,111), i.e. the platform libm, whose
-// last-bit behaviour is not defined by the reference.  A one-ulp difference in a
-// sampled direction flips hemisphere / Russian-roulette branches and changes a
-// whole path, so this library fixes the function instead: evaluate in binary64
-// with the fdlibm minimax kernels using only + - * / sqrt (each correctly
-// rounded on x86-64 and on CDNA4; -ffp-contract=off keeps them unfused) and
-// round once to binary32.  f64 vector throughput on MI355X is half the f32
-// rate, and a bounce needs two or three of these calls: negligible next to BVH
-// traversal.
+// spot_light.rs:33-34, sphere.rs:90,102,111), i.e. the platform libm — on x86-64 Linux
+// glibc's sinf / cosf / tanf / logf / acosf / atan2f.  A one-ulp difference in a sampled
+// direction flips hemisphere / Russian-roulette branches and changes a whole path, so
+// "some correct libm" is not enough: these are glibc 2.35's algorithms themselves, every
+// operation in the order (and with the fusing) of its x86-64 build — binary64 multiply /
+// fused multiply-add / conversions for sin, cos, log and the reduction of tan; binary32
+// + - * / sqrt (correctly rounded on x86-64 and on CDNA4, -ffp-contract=off keeps them
+// unfused) for acos, atan, atan2 and the tan kernel.  oracle/olibm.h holds the same
+// restatement for the CPU oracle and is checked against the platform's functions for all
+// 2^32 arguments (tools/micro/glibc_libm_check.cpp, profiles/r03_glibc_libm_check.txt);
+// the device instance of this file is compared with the oracle's on the GPU
+// (tests/test_gpu_stages.py).  A bounce needs two or three of these calls: negligible
+// next to BVH traversal.
 #pragma once
 #include "yk_math.h"
 
 namespace yk {
 
-YK_HD double poly_sin(double r) {
-    double z = r * r;
-    double p = 8.33333333332248946124e-03 +
-               z * (-1.98412698298579493134e-04 +
-                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
-    return r + (r * z) * (-1.66666666666666324348e-01 + z * p);
+// ---------------------------------------------------------------------------------------------------------------
+// sinf / cosf: glibc's own algorithm (s_sinf.c / s_cosf.c / sincosf.h: the single-precision routines glibc ships since 2.28), in the
+// operation order of its x86-64 FMA build — the function Rust's f32::sin / f32::cos resolve to on every Linux machine with FMA3.
+// Exact arithmetic only (binary64 multiply, fused multiply-add, conversions; integer arithmetic in the large-argument reduction):
+// the same bits on the host and on gfx950.  The oracle's copy (oracle/olibm.h) equals the platform's functions for all 2^32
+// arguments (profiles/r03_glibc_sincos_check.txt); this one equals the oracle's for all 2^32 arguments on the device
+// (tests/test_gpu_stages.py).  The second coefficient table of glibc (quadrants whose result is negated) is the first with the
+// cosine coefficients negated — negation is exact, so `neg ? -c : c` is that table.
+YK_HD float gl_poly_sin(double xs, double x2) {
+    double s1 = fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+    double x3 = x2 * xs;
+    double x7 = x2 * x3;
+    double s = fma(x3, -0x1.555545995a603p-3, xs);
+    return (float)fma(s1, x7, s);
 }
-
-YK_HD double poly_cos(double r) {
-    double z = r * r;
-    double p =
-        z * (4.16666666666666019037e-02 +
-             z * (-1.38888888888741095749e-03 +
-                  z * (2.48015872894767294178e-05 +
-                       z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
-    return (1.0 - 0.5 * z) + z * p;
+YK_HD float gl_poly_cos(double x2, bool neg) {
+    const double c0 = neg ? -0x1p0 : 0x1p0, c1 = neg ? 0x1.ffffffd0c621cp-2 : -0x1.ffffffd0c621cp-2, c2 = neg ? -0x1.55553e1068f19p-5 : 0x1.55553e1068f19p-5,
+                 c3 = neg ? 0x1.6c087e89a359dp-10 : -0x1.6c087e89a359dp-10, c4 = neg ? -0x1.99343027bf8c3p-16 : 0x1.99343027bf8c3p-16;
+    double x4 = x2 * x2;
+    double a = fma(x2, c1, c0);
+    double b = fma(x2, c4, c3);
+    double x6 = x2 * x4;
+    double c = fma(x4, c2, a);
+    return (float)fma(b, x6, c);
 }
-
-// x = n*(pi/2) + r with |r| <= pi/4 (+eps); Cody-Waite, pi/2 split in three
-YK_HD double quadrant_reduce(double x, int& quadrant) {
-    double fn = floor(x * 6.36619772367581382433e-01 + 0.5);
-    double r = x - fn * 1.57079632673412561417e+00;
-    r = r - fn * 6.07710050630396597660e-11;
-    r = r - fn * 2.02226624879595063154e-21;
-    quadrant = (int)((long long)fn & 3);
-    return r;
+// reduce_fast (|x| < 120): n = round(x / (pi/2)) through the 2^24-scaled product; x - n * pi/2 in one fused step
+YK_HD double gl_reduce_fast(double x, int& n) {
+    double r = x * 0x1.45F306DC9C883p+23;
+    n = ((int)r + 0x800000) >> 24;
+    return fma(-(double)n, 0x1.921FB54442D18p0, x);
+}
+// __inv_pio4[k]: 32 bits of 4/pi ending at byte k of its bit string (a2 f9 83 6e 4e 44 15 29 fc 27 57 d1 f5 34 dd c0 db 62 95 99 3c 43 90 41)
+YK_HD unsigned gl_inv_pio4(int k) {
+    const unsigned long long w0 = 0xa2f9836e4e441529ull, w1 = 0xfc2757d1f534ddc0ull, w2 = 0xdb6295993c439041ull;
+    unsigned v = 0;
+    for (int j = 3; j >= 0; --j) {
+        const int i = k - j;  // byte index, most significant first
+        unsigned byte = 0;
+        if (i >= 0) {
+            const unsigned long long w = i < 8 ? w0 : (i < 16 ? w1 : w2);
+            byte = (unsigned)(w >> (8 * (7 - (i & 7)))) & 0xffu;
+        }
+        v = (v << 8) | byte;
+    }
+    return v;
+}
+// reduce_large (120 <= |x| < inf): the 24 mantissa bits times 96 bits of 4/pi
+YK_HD double gl_reduce_large(unsigned xi, int& n) {
+    const int k = (int)((xi >> 26) & 15u);
+    const int shift = (int)((xi >> 23) & 7u);
+    xi = (xi & 0xffffffu) | 0x800000u;
+    xi <<= shift;
+    unsigned long long res0 = (unsigned long long)(unsigned)(xi * gl_inv_pio4(k));
+    const unsigned long long res1 = (unsigned long long)xi * gl_inv_pio4(k + 4);
+    const unsigned long long res2 = (unsigned long long)xi * gl_inv_pio4(k + 8);
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const unsigned long long nn = (res0 + (1ull << 61)) >> 62;
+    res0 -= nn << 62;
+    n = (int)nn;
+    return (double)(long long)res0 * 0x1.921FB54442D18p-62;
+}
+// both functions: quadrant n, sign of the reduced argument, which polynomial
+YK_HD float gl_sincosf(float y, int want_cos) {
+    union {
+        float f;
+        unsigned u;
+    } cv;
+    cv.f = y;
+    const unsigned xi = cv.u, top = (xi >> 20) & 0x7ffu;
+    double x = (double)y;
+    if (top < 0x3f4u) {  // |y| < pi/4
+        if (top < 0x398u) return want_cos ? 1.0f : y;  // |y| < 2^-12
+        return want_cos ? gl_poly_cos(x * x, false) : gl_poly_sin(x, x * x);
+    }
+    int n, sign = 0;
+    if (top < 0x42fu) {
+        x = gl_reduce_fast(x, n);
+    } else if (top < 0x7f8u) {
+        sign = (int)(xi >> 31);
+        x = gl_reduce_large(xi, n);
+    } else {
+        return y - y;  // inf, NaN
+    }
+    const int q = (n + sign) & 3;
+    const double s = (q == 1 || q == 2) ? -1.0 : 1.0;
+    const bool neg = ((n + sign) & 2) != 0;
+    const bool use_cos = ((n ^ want_cos) & 1) != 0;
+    return use_cos ? gl_poly_cos(x * x, neg) : gl_poly_sin(x * s, x * x);
 }
 
 YK_HD float det_sinf(float xf) {
-#if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)  // timing builds only: the hardware approximations instead of the f64 recipe
+#if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)  // timing builds only: the hardware approximations instead
     return __sinf(xf);
 #endif
-    double x = (double)xf;
-    if (!(fabs(x) < 1.0e300)) return xf - xf;
-    int q;
-    double r = quadrant_reduce(x, q);
-    double v = (q & 1) ? poly_cos(r) : poly_sin(r);
-    return (float)((q & 2) ? -v : v);
+    return gl_sincosf(xf, 0);
 }
 
 YK_HD float det_cosf(float xf) {
-#if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)  // timing builds only: the hardware approximations instead of the f64 recipe
+#if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)  // timing builds only: the hardware approximations instead
     return __cosf(xf);
 #endif
-    double x = (double)xf;
-    if (!(fabs(x) < 1.0e300)) return xf - xf;
-    int q;
-    double r = quadrant_reduce(x, q);
-    double v = (q & 1) ? poly_sin(r) : poly_cos(r);
-    return (float)(((q + 1) & 2) ? -v : v);
+    return gl_sincosf(xf, 1);
+}
+
+YK_HD float gl_from_bits(unsigned b) { return __builtin_bit_cast(float, b); }
+YK_HD unsigned gl_to_bits(float f) { return __builtin_bit_cast(unsigned, f); }
+
+// logf (e_logf.c of glibc >= 2.27, the `__logf_fma` build): 16-entry table of 1/c and log c, a cubic in binary64, one rounding
+YK_HD void gl_logf_entry(int i, double& invc, double& logc) {
+    switch (i) {
+        case 0: invc = 0x1.661ec79f8f3bep+0; logc = -0x1.57bf7808caadep-2; break;
+        case 1: invc = 0x1.571ed4aaf883dp+0; logc = -0x1.2bef0a7c06ddbp-2; break;
+        case 2: invc = 0x1.49539f0f010bp+0; logc = -0x1.01eae7f513a67p-2; break;
+        case 3: invc = 0x1.3c995b0b80385p+0; logc = -0x1.b31d8a68224e9p-3; break;
+        case 4: invc = 0x1.30d190c8864a5p+0; logc = -0x1.6574f0ac07758p-3; break;
+        case 5: invc = 0x1.25e227b0b8eap+0; logc = -0x1.1aa2bc79c81p-3; break;
+        case 6: invc = 0x1.1bb4a4a1a343fp+0; logc = -0x1.a4e76ce8c0e5ep-4; break;
+        case 7: invc = 0x1.12358f08ae5bap+0; logc = -0x1.1973c5a611cccp-4; break;
+        case 8: invc = 0x1.0953f419900a7p+0; logc = -0x1.252f438e10c1ep-5; break;
+        case 9: invc = 0x1p+0; logc = 0x0p+0; break;
+        case 10: invc = 0x1.e608cfd9a47acp-1; logc = 0x1.aa5aa5df25984p-5; break;
+        case 11: invc = 0x1.ca4b31f026aap-1; logc = 0x1.c5e53aa362eb4p-4; break;
+        case 12: invc = 0x1.b2036576afce6p-1; logc = 0x1.526e57720db08p-3; break;
+        case 13: invc = 0x1.9c2d163a1aa2dp-1; logc = 0x1.bc2860d22477p-3; break;
+        case 14: invc = 0x1.886e6037841edp-1; logc = 0x1.1058bc8a07ee1p-2; break;
+        default: invc = 0x1.767dcf5534862p-1; logc = 0x1.4043057b6ee09p-2; break;
+    }
+}
+YK_HD float gl_logf(float xf) {
+    unsigned ix = gl_to_bits(xf);
+    if (ix == 0x3f800000u) return 0.0f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {  // zero, subnormal, negative, inf, NaN
+        if (ix * 2u == 0u) return -1.0f / 0.0f;
+        if (ix == 0x7f800000u) return xf;
+        if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return (xf - xf) / 0.0f;
+        ix = gl_to_bits(xf * 0x1p23f) - (23u << 23);
+    }
+    const unsigned tmp = ix - 0x3f330000u;
+    const int k = (int)tmp >> 23;
+    double invc, logc;
+    gl_logf_entry((int)((tmp >> 19) & 15u), invc, logc);
+    const double z = (double)gl_from_bits(ix - (tmp & 0xff800000u));
+    const double r = fma(z, invc, -1.0);
+    const double y0 = fma((double)k, 0x1.62e42fefa39efp-1, logc);
+    const double r2 = r * r;
+    double y = fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
+    y = fma(-0x1.00ea348b88334p-2, r2, y);
+    return (float)fma(y, r2, y0 + r);
+}
+
+// acosf (e_acosf.c, binary32 fdlibm): rational p/q on [0, 0.5], sqrt form with a split root above
+YK_HD float gl_acos_ratio(float z) {
+    const float p = z * (gl_from_bits(0x3e2aaaabu) +
+                         z * (gl_from_bits(0xbea6b090u) +
+                              z * (gl_from_bits(0x3e4e0aa8u) + z * (gl_from_bits(0xbd241146u) + z * (gl_from_bits(0x3a4f7f04u) + z * gl_from_bits(0x3811ef08u))))));
+    const float q = 1.0f + z * (gl_from_bits(0xc019d139u) + z * (gl_from_bits(0x4001572du) + z * (gl_from_bits(0xbf303361u) + z * gl_from_bits(0x3d9dc62eu))));
+    return p / q;
+}
+YK_HD float gl_acosf(float x) {
+    const float pi = gl_from_bits(0x40490fdau), pio2_hi = gl_from_bits(0x3fc90fdau), pio2_lo = gl_from_bits(0x33a22168u);
+    const int hx = (int)gl_to_bits(x), ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
+    if (ix > 0x3f800000) return (x - x) / (x - x);
+    if (ix < 0x3f000000) {
+        if (ix <= 0x32800000) return pio2_hi + pio2_lo;
+        const float r = gl_acos_ratio(x * x);
+        return pio2_hi - (x - (pio2_lo - r * x));
+    }
+    if (hx < 0) {
+        const float z = (1.0f + x) * 0.5f;
+        const float r = gl_acos_ratio(z);
+        const float s = sqrtf(z);
+        const float w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    }
+    const float z = (1.0f - x) * 0.5f;
+    const float s = sqrtf(z);
+    const float df = gl_from_bits(gl_to_bits(s) & 0xfffff000u);
+    const float c = (z - df * df) / (s + df);
+    const float r = gl_acos_ratio(z);
+    const float w = r * s + c;
+    return 2.0f * (df + w);
+}
+
+// atanf (s_atanf.c): four breakpoints, odd / even halves of an 11-term polynomial
+YK_HD float gl_atanf(float x) {
+    const int hx = (int)gl_to_bits(x), ix = hx & 0x7fffffff;
+    float hi = 0.0f, lo = 0.0f;
+    bool reduced = true;
+    if (ix >= 0x4c000000) {  // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;
+        return hx > 0 ? gl_from_bits(0x3fc90fdau) + gl_from_bits(0x33a22168u) : -gl_from_bits(0x3fc90fdau) - gl_from_bits(0x33a22168u);
+    }
+    if (ix < 0x3ee00000) {
+        if (ix < 0x31000000) return x;
+        reduced = false;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f300000) {
+            hi = gl_from_bits(0x3eed6338u);
+            lo = gl_from_bits(0x31ac3769u);
+            x = (2.0f * x - 1.0f) / (2.0f + x);
+        } else if (ix < 0x3f980000) {
+            hi = gl_from_bits(0x3f490fdau);
+            lo = gl_from_bits(0x33222168u);
+            x = (x - 1.0f) / (x + 1.0f);
+        } else if (ix < 0x401c0000) {
+            hi = gl_from_bits(0x3f7b985eu);
+            lo = gl_from_bits(0x33140fb4u);
+            x = (x - 1.5f) / (1.0f + 1.5f * x);
+        } else {
+            hi = gl_from_bits(0x3fc90fdau);
+            lo = gl_from_bits(0x33a22168u);
+            x = -1.0f / x;
+        }
+    }
+    const float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (gl_from_bits(0x3eaaaaabu) +
+                          w * (gl_from_bits(0x3e124925u) +
+                               w * (gl_from_bits(0x3dba2e6eu) + w * (gl_from_bits(0x3d886b35u) + w * (gl_from_bits(0x3d4bda59u) + w * gl_from_bits(0x3c8569d7u))))));
+    const float s2 = w * (gl_from_bits(0xbe4ccccdu) +
+                          w * (gl_from_bits(0xbde38e38u) + w * (gl_from_bits(0xbd9d8795u) + w * (gl_from_bits(0xbd6ef16bu) + w * gl_from_bits(0xbd15a221u)))));
+    if (!reduced) return x - x * (s1 + s2);
+    const float r = hi - ((x * (s1 + s2) - lo) - x);
+    return hx < 0 ? -r : r;
+}
+
+// atan2f (e_atan2f.c): the special cases, then atanf(|y / x|) moved to the quadrant
+YK_HD float gl_atan2f(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = gl_from_bits(0x3f490fdbu), pi_o_2 = gl_from_bits(0x3fc90fdbu), pi = gl_from_bits(0x40490fdbu),
+                pi_lo = gl_from_bits(0xb3bbbd2eu);
+    const int hx = (int)gl_to_bits(x), hy = (int)gl_to_bits(y), ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return gl_atanf(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) {
+        if (m < 2) return y;
+        return m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) {
+            if (m == 0) return pi_o_4 + tiny;
+            if (m == 1) return -pi_o_4 - tiny;
+            if (m == 2) return 3.0f * pi_o_4 + tiny;
+            return -3.0f * pi_o_4 - tiny;
+        }
+        if (m == 0) return 0.0f;
+        if (m == 1) return -0.0f;
+        if (m == 2) return pi + tiny;
+        return -pi - tiny;
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60)
+        z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60)
+        z = 0.0f;
+    else
+        z = gl_atanf(fabsf(y / x));
+    if (m == 0) return z;
+    if (m == 1) return gl_from_bits(gl_to_bits(z) ^ 0x80000000u);
+    if (m == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
+}
+
+// __kernel_tanf (k_tanf.c): tan(x + y) on |x + y| <= pi/4 for iy = 1, -1 / tan(x + y) for iy = -1
+YK_HD float gl_kernel_tanf(float x, float y, int iy) {
+    const float pio4 = gl_from_bits(0x3f490fdau), pio4lo = gl_from_bits(0x33222168u);
+    const int hx = (int)gl_to_bits(x), ix = hx & 0x7fffffff;
+    if (ix < 0x39000000) {  // |x| < 2^-13
+        if ((ix | (iy + 1)) == 0) return 1.0f / fabsf(x);
+        return iy == 1 ? x : -1.0f / x;
+    }
+    if (ix >= 0x3f2ca140) {  // |x| >= 0.6744
+        if (hx < 0) {
+            x = -x;
+            y = -y;
+        }
+        const float z = pio4 - x;
+        const float w = pio4lo - y;
+        x = z + w;
+        y = 0.0f;
+        if (fabsf(x) < 0x1p-13f) return (float)((1 - ((hx >> 30) & 2)) * iy) * (1.0f - (float)(2 * iy) * x);
+    }
+    const float z = x * x;
+    float w = z * z;
+    float r = gl_from_bits(0x3e088889u) +
+              w * (gl_from_bits(0x3cb327a4u) +
+                   w * (gl_from_bits(0x3b6b6916u) + w * (gl_from_bits(0x3a1a26c8u) + w * (gl_from_bits(0x38a3f445u) + w * gl_from_bits(0xb79bae5fu)))));
+    float v = z * (gl_from_bits(0x3d5d0dd1u) +
+                   w * (gl_from_bits(0x3c11371fu) +
+                        w * (gl_from_bits(0x3abede48u) + w * (gl_from_bits(0x398137b9u) + w * (gl_from_bits(0x3895c07au) + w * gl_from_bits(0x37d95384u))))));
+    float s = z * x;
+    r = y + z * (s * (r + v) + y);
+    r += gl_from_bits(0x3eaaaaabu) * s;
+    w = x + r;
+    if (ix >= 0x3f2ca140) {
+        v = (float)iy;
+        return (float)(1 - ((hx >> 30) & 2)) * (v - 2.0f * (x - (w * w / (w + v) - r)));
+    }
+    if (iy == 1) return w;
+    const float zz = gl_from_bits(gl_to_bits(w) & 0xfffff000u);
+    v = r - (zz - x);
+    const float a = -1.0f / w;
+    const float t = gl_from_bits(gl_to_bits(a) & 0xfffff000u);
+    s = 1.0f + t * zz;
+    return t + a * (s + t * v);
+}
+
+// tanf (s_tanf.c of glibc 2.35): sincosf.h's reductions, unfused in this function, the remainder split into a binary32 head and tail
+YK_HD float gl_tanf(float x) {
+    const int hx = (int)gl_to_bits(x), ix = hx & 0x7fffffff;
+    if (ix <= 0x3f490fda) return gl_kernel_tanf(x, 0.0f, 1);
+    if (ix >= 0x7f800000) return x - x;
+    double dx = (double)x;
+    int n;
+    if ((((unsigned)hx >> 20) & 0x7ffu) < 0x42fu) {  // |x| < 120
+        const double r = dx * 0x1.45F306DC9C883p+23;
+        n = ((int)r + 0x800000) >> 24;
+        dx = dx - (double)n * 0x1.921FB54442D18p0;
+    } else {
+        dx = gl_reduce_large((unsigned)hx, n);
+        if (hx < 0) dx = -dx;
+    }
+    const float y0 = (float)dx;
+    const float y1 = (float)(dx - (double)y0);
+    return gl_kernel_tanf(y0, y1, 1 - ((n & 1) << 1));
 }
 
 YK_HD float det_tanf(float xf) {
-#if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)  // timing builds only: the hardware approximations instead of the f64 recipe
+#if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)  // timing builds only: the hardware approximations instead
     return __tanf(xf);
 #endif
-    double x = (double)xf;
-    if (!(fabs(x) < 1.0e300)) return xf - xf;
-    int q;
-    double r = quadrant_reduce(x, q);
-    double s = poly_sin(r), c = poly_cos(r);
-    return (float)((q & 1) ? -(c / s) : (s / c));
+    return gl_tanf(xf);
 }
 
 YK_HD float det_logf(float xf) {
-#if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)  // timing builds only: the hardware approximations instead of the f64 recipe
+#if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)  // timing builds only: the hardware approximations instead
     return __logf(xf);
 #endif
-    if (xf != xf) return xf;
-    if (xf < 0.0f) return (xf - xf) / 0.0f;
-    if (xf == 0.0f) return -1.0f / 0.0f;
-    if (xf > 3.0e38f && xf + xf == xf) return xf;
-    double x = (double)xf;
-    unsigned long long bits = (unsigned long long)__builtin_bit_cast(unsigned long long, x);
-    long long e = (long long)((bits >> 52) & 0x7ff) - 1023;
-    bits = (bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
-    double m = __builtin_bit_cast(double, bits);
-    if (m > 1.41421356237309514547) {
-        m = m * 0.5;
-        e += 1;
-    }
-    double f = m - 1.0;
-    double s = f / (2.0 + f);
-    double z = s * s;
-    double R = z * (6.666666666666735130e-01 +
-                    z * (3.999999999940941908e-01 +
-                         z * (2.857142874366239149e-01 +
-                              z * (2.222219843214978396e-01 +
-                                   z * (1.818357216161805012e-01 + z * (1.531383769920937332e-01 + z * 1.479819860511658591e-01))))));
-    double lg = 2.0 * s + s * R;
-    return (float)((double)e * 6.93147180559945286227e-01 + lg);
+    return gl_logf(xf);
 }
 
-// atan for x >= 0 in binary64
-YK_HD double atan_nonneg(double x) {
-    double hi = 0.0, lo = 0.0;
-    int reduced = 1;
-    if (x < 0.4375) {
-        reduced = 0;
-    } else if (x < 0.6875) {
-        hi = 4.63647609000806093515e-01;
-        lo = 2.26987774529616870924e-17;
-        x = (2.0 * x - 1.0) / (2.0 + x);
-    } else if (x < 1.1875) {
-        hi = 7.85398163397448278999e-01;
-        lo = 3.06161699786838301793e-17;
-        x = (x - 1.0) / (x + 1.0);
-    } else if (x < 2.4375) {
-        hi = 9.82793723247329054082e-01;
-        lo = 1.39033110312309984516e-17;
-        x = (x - 1.5) / (1.0 + 1.5 * x);
-    } else {
-        hi = 1.57079632679489655800e+00;
-        lo = 6.12323399573676603587e-17;
-        x = -1.0 / x;
-    }
-    double z = x * x;
-    double w = z * z;
-    double s1 = z * (3.33333333333329318027e-01 +
-                     w * (1.42857142725034663711e-01 +
-                          w * (9.09088713343650656196e-02 +
-                               w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
-    double s2 = w * (-1.99999999998764832476e-01 +
-                     w * (-1.11111104054623557880e-01 +
-                          w * (-7.69187620504482999495e-02 + w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
-    if (!reduced) return x - x * (s1 + s2);
-    return hi - ((x * (s1 + s2) - lo) - x);
-}
+YK_HD float det_atan2f(float yf, float xf) { return gl_atan2f(yf, xf); }
 
-YK_HD float det_atan2f(float yf, float xf) {
-    const double PI = 3.14159265358979311600e+00, PIO2 = 1.57079632679489655800e+00;
-    if (xf != xf || yf != yf) return xf + yf;
-    double y = (double)yf, x = (double)xf;
-    if (y == 0.0) {
-        double v = __builtin_signbit(xf) ? PI : 0.0;
-        return (float)(__builtin_signbit(yf) ? -v : v);
-    }
-    if (x == 0.0) return (float)(y > 0.0 ? PIO2 : -PIO2);
-    double ax = fabs(x), ay = fabs(y), a;
-    if (ax > 1.0e300 && ay > 1.0e300)
-        a = 7.85398163397448278999e-01;
-    else if (ay > 1.0e300)
-        a = PIO2;
-    else if (ax > 1.0e300)
-        a = 0.0;
-    else
-        a = atan_nonneg(ay / ax);
-    if (x < 0.0) a = PI - a;
-    return (float)(y < 0.0 ? -a : a);
-}
-
-YK_HD float det_acosf(float xf) {
-    if (xf != xf) return xf;
-    double x = (double)xf;
-    if (x > 1.0 || x < -1.0) return (xf - xf) / (xf - xf);
-    double a = sqrt(1.0 - x), b = sqrt(1.0 + x);
-    double t = (b == 0.0) ? 1.57079632679489655800e+00 : atan_nonneg(a / b);
-    return (float)(2.0 * t);
-}
+YK_HD float det_acosf(float xf) { return gl_acosf(xf); }
 
 }  // namespace yk

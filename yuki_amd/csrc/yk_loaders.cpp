@@ -573,7 +573,7 @@ const float COPPER_K[56] = {1.662125f, 1.687f, 1.703313f, 1.72f, 1.744563f, 1.77
     2.469187f, 2.504f, 2.535875f, 2.564f, 2.589625f, 2.605f, 2.595562f, 2.583f, 2.5765f, 2.599f, 2.678062f, 2.809f, 3.01075f, 3.24f, 3.458187f, 3.67f,
     3.863125f, 4.05f, 4.239563f, 4.43f, 4.619563f, 4.817f, 5.034125f, 5.26f, 5.485625f, 5.717f};
 
-// transforms::rotation, math/transforms.rs:98-127 (sin/cos through the shared libm recipe)
+// transforms::rotation, math/transforms.rs:98-127 (sin/cos through yk_libm.h: glibc's sinf / cosf)
 Xf xf_rotation(float theta, V3 axis) {
     V3 a = normalize(axis);
     float c = det_cosf(theta), s = det_sinf(theta);
