@@ -92,6 +92,8 @@ def lib():
         f.restype = C.c_float
     L.orc_libm_array.argtypes = [C.c_int, C.c_size_t, vp, vp, vp]
     L.orc_libm_array.restype = None
+    L.orc_expf.argtypes = [C.c_float]
+    L.orc_expf.restype = C.c_float
     L.orc_atan2f.argtypes = [C.c_float, C.c_float]
     L.orc_atan2f.restype = C.c_float
     L.orc_mat4_inverse_f32.argtypes = [vp, vp]
@@ -279,7 +281,7 @@ def detile(tiles, rgb, res):
 
 
 def libm_array(fn, x, y=None):
-    """olibm.h over an array: fn 0 sin, 1 cos, 2 tan, 3 log, 4 acos, 5 atan2(x, y)."""
+    """olibm.h over an array: fn 0 sin, 1 cos, 2 tan, 3 log, 4 acos, 5 atan2(x, y), 6 exp."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     yy = None if y is None else np.ascontiguousarray(y, dtype=np.float32)
     out = np.zeros_like(x)

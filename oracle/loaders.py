@@ -420,7 +420,8 @@ class _Lexer:
 
 
 def _expf(x):
-    return F(math.exp(float(x)))
+    """f32::exp (pbrt/cie.rs:8-20) = the platform's expf: oracle/olibm.h's restatement of glibc 2.35's."""
+    return F(binding.lib().orc_expf(float(x)))
 
 
 def _fit(l, terms):

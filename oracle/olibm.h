@@ -8,8 +8,8 @@
 // into a different path, so the oracle and the HIP kernels must use the *same* function —
 // and to be the reference's image rather than "an" image it has to be the function the
 // reference calls.  On x86-64 Linux that is glibc; namespace glibc below restates glibc
-// 2.35's sinf, cosf, tanf, logf, acosf, atanf and atan2f operation by operation (published
-// sources: sysdeps/ieee754/flt-32/{s_sinf,s_cosf,s_tanf,k_tanf,e_logf,e_acosf,s_atanf,
+// 2.35's sinf, cosf, tanf, logf, expf, acosf, atanf and atan2f operation by operation (published
+// sources: sysdeps/ieee754/flt-32/{s_sinf,s_cosf,s_tanf,k_tanf,e_logf,e_expf,e_acosf,s_atanf,
 // e_atan2f}.c, sincosf.h; order and fusing read off the instructions of libm.so.6's x86-64
 // build, FMA variants where glibc dispatches to them).  glibc is not under /root/reference
 // — it is the reference's platform dependency — so the pin is the platform's own binary:
@@ -387,6 +387,41 @@ inline float tanf(float x) {
     return kernel_tanf(y0, y1, 1 - ((n & 1) << 1));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// expf (e_expf.c + e_exp2f_data.c, `__expf_fma`; the pbrt loader's CIE fits, pbrt/cie.rs:8-20): 2^(k/32) from a table, a cubic in
+// binary64.  Fused where the FMA build fuses: kd = fma(InvLn2N, x, SHIFT) and r = fma(InvLn2N, x, -kd) — the product x * InvLn2N
+// is never rounded on its own.
+static const uint64_t exp2f_tab[32] = {
+    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b, 0x3fef54873168b9aa, 0x3fef387a6e756238, 0x3fef1e9df51fdee1,
+    0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d, 0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429, 0x3feea47eb03a5585,
+    0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74, 0x3feea11473eb0187, 0x3feea589994cce13, 0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d,
+    0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f, 0x3fefa4afa2a490da, 0x3fefd0765b6e4540};
+inline float expf(float x) {
+    const uint32_t ix = to_bits(x), abstop = (ix >> 20) & 0x7ffu;
+    const double xd = (double)x;
+    if (abstop >= 0x42bu) {  // |x| >= 88 or NaN
+        if (ix == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8u) return x + x;
+        if (x > 0x1.62e42ep6f) return 0x1p97f * 0x1p97f;            // overflow
+        if (x < -0x1.9fe368p6f) return 0x1p-95f * 0x1p-95f;         // underflow to +0
+        if (x < -0x1.9d1d9ep6f) return 0x1.4p-75f * 0x1.4p-75f;     // the smallest denormal
+    }
+    const double shift = 0x1.8p+52, inv_ln2n = 0x1.71547652b82fep+5;
+    double kd = std::fma(inv_ln2n, xd, shift);
+    uint64_t ki;
+    std::memcpy(&ki, &kd, 8);
+    kd -= shift;
+    const double r = std::fma(inv_ln2n, xd, -kd);
+    const uint64_t t = exp2f_tab[ki & 31u] + (ki << 47);
+    double s;
+    std::memcpy(&s, &t, 8);
+    const double z = std::fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
+    const double r2 = r * r;
+    double y = std::fma(0x1.62e42ff0c52d6p-6, r, 1.0);
+    y = std::fma(z, r2, y);
+    return (float)(y * s);
+}
+
 }  // namespace glibc
 
 inline float sinf_(float xf) {
@@ -415,6 +450,13 @@ inline float logf_(float xf) {
     return ::logf(xf);
 #endif
     return glibc::logf(xf);
+}
+
+inline float expf_(float xf) {
+#if defined(ORC_HOST_LIBM) && (!defined(ORC_HOST_LIBM_ONLY) || ((ORC_HOST_LIBM_ONLY) & 16))
+    return ::expf(xf);
+#endif
+    return glibc::expf(xf);
 }
 
 inline float atan2f_(float yf, float xf) {

@@ -462,7 +462,8 @@ float orc_tanf(float x) { return lm::tanf_(x); }
 float orc_logf(float x) { return lm::logf_(x); }
 float orc_atan2f(float y, float x) { return lm::atan2f_(y, x); }
 float orc_acosf(float x) { return lm::acosf_(x); }
-// fn 0 sin, 1 cos, 2 tan, 3 log, 4 acos, 5 atan2(x[i], y[i]) over arrays (the exhaustive comparisons of tests/ and tools/)
+float orc_expf(float x) { return lm::expf_(x); }
+// fn 0 sin, 1 cos, 2 tan, 3 log, 4 acos, 5 atan2(x[i], y[i]), 6 exp over arrays (the exhaustive comparisons of tests/ and tools/)
 void orc_libm_array(int fn, size_t n, const float* x, const float* y, float* out) {
     for (size_t i = 0; i < n; ++i) {
         switch (fn) {
@@ -471,6 +472,7 @@ void orc_libm_array(int fn, size_t n, const float* x, const float* y, float* out
             case 2: out[i] = lm::tanf_(x[i]); break;
             case 3: out[i] = lm::logf_(x[i]); break;
             case 4: out[i] = lm::acosf_(x[i]); break;
+            case 6: out[i] = lm::expf_(x[i]); break;
             default: out[i] = lm::atan2f_(x[i], y ? y[i] : 0.0f); break;
         }
     }

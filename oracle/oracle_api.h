@@ -181,6 +181,7 @@ float orc_tanf(float x);
 float orc_logf(float x);
 float orc_atan2f(float y, float x);
 float orc_acosf(float x);
+float orc_expf(float x);
 void orc_libm_array(int fn, size_t n, const float* x, const float* y, float* out);
 
 /* math KAT hooks (replay of the reference's tests/src/ *.rs) */

@@ -1,5 +1,5 @@
 """The oracle's libm (oracle/olibm.h) against what the Rust reference calls on Linux, the
-platform's glibc: all six functions restate glibc 2.35's own algorithms (sinf / cosf / logf in
+platform's glibc: all seven functions restate glibc 2.35's own algorithms (sinf / cosf / logf / expf in
 the FMA variants every x86-64 host with FMA3 dispatches to) and must be bit-equal to them.
 The exhaustive 2^32 comparison is tools/micro/glibc_libm_check.cpp
 (profiles/r03_glibc_libm_check.txt); the strided one here runs in seconds.  Accuracy against
@@ -17,7 +17,7 @@ def _host_libm():
     if path is None:
         pytest.skip("no libm to compare with")
     L = ctypes.CDLL(path)
-    for n in ("sinf", "cosf", "tanf", "logf", "acosf"):
+    for n in ("sinf", "cosf", "tanf", "logf", "acosf", "expf"):
         getattr(L, n).argtypes = [ctypes.c_float]
         getattr(L, n).restype = ctypes.c_float
     L.atan2f.argtypes = [ctypes.c_float, ctypes.c_float]
@@ -63,6 +63,8 @@ def test_libm_accuracy_bounds(oracle):
         assert _ulp_diff(oracle.libm_array(fn, x), ref64(x64).astype(np.float32)).max() <= bound, fn
     p = (np.abs(x) + 1e-6).astype(np.float32)
     assert _ulp_diff(oracle.libm_array(3, p), np.log(p.astype(np.float64)).astype(np.float32)).max() <= 1
+    e = rng.uniform(-100, 80, 20000).astype(np.float32)
+    assert _ulp_diff(oracle.libm_array(6, e), np.exp(e.astype(np.float64)).astype(np.float32)).max() <= 1
     c = rng.uniform(-1, 1, 20000).astype(np.float32)
     assert _ulp_diff(oracle.libm_array(4, c), np.arccos(c.astype(np.float64)).astype(np.float32)).max() <= 1
     y = rng.uniform(-3, 3, 20000).astype(np.float32)
@@ -73,9 +75,9 @@ def _same(a, b):
     return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
 
 
-def test_the_six_functions_are_the_platform_libms_bit_for_bit(oracle):
-    """What `f32::{sin,cos,tan,ln,acos,atan2}` lower to in the reference on Linux (sampling/mod.rs:62-87,
-    trowbridge_reitz.rs:23-30, camera.rs:52-102, sphere.rs:38-119): glibc's functions.  Every 65,521st float
+def test_the_libm_functions_are_the_platform_libms_bit_for_bit(oracle):
+    """What `f32::{sin,cos,tan,ln,exp,acos,atan2}` lower to in the reference on Linux (sampling/mod.rs:62-87,
+    trowbridge_reitz.rs:23-30, camera.rs:52-102, sphere.rs:38-119, pbrt/cie.rs:8-20): glibc's functions.  Every 65,521st float
     (65,548 arguments across all exponents, both signs, NaN / inf / denormals included) plus 100,000 random ones
     in the range the renderer uses; atan2f on 165,548 pairs."""
     if not _host_has_fma():
@@ -88,7 +90,7 @@ def test_the_six_functions_are_the_platform_libms_bit_for_bit(oracle):
     rng = np.random.default_rng(77)
     x = np.concatenate([bits.view(np.float32), rng.uniform(-7, 7, 100000).astype(np.float32),
                         np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 3.4e38, 0.785398185, 1.57079637, 1.0, -1.0, 0.5, -0.5], np.float32)])
-    for fn, name in ((0, "sinf"), (1, "cosf"), (2, "tanf"), (3, "logf"), (4, "acosf")):
+    for fn, name in ((0, "sinf"), (1, "cosf"), (2, "tanf"), (3, "logf"), (4, "acosf"), (6, "expf")):
         got = oracle.libm_array(fn, x)
         f = getattr(host, name)
         want = np.array([f(float(a)) for a in x], dtype=np.float32)

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 from yuki_amd import core as yk  # noqa: E402
 from oracle import binding as oracle  # noqa: E402
 
-NAMES = ["sinf", "cosf", "tanf", "logf", "acosf", "atan2f"]
+NAMES = ["sinf", "cosf", "tanf", "logf", "acosf", "atan2f", "expf"]  # expf: host side only (the pbrt loader), oracle vs platform libm
 
 
 def same(a, b):
@@ -44,9 +44,9 @@ def main():
     a = ap.parse_args()
     ctx = yk.Context(0)
     pool = ThreadPoolExecutor(a.workers)
-    dev_bad = [0] * 6
-    host_bad = [0] * 6
-    count = [0] * 6
+    dev_bad = [0] * 7
+    host_bad = [0] * 7
+    count = [0] * 7
     first = {}
     t0 = time.time()
     total = (1 << 32) // a.stride
@@ -55,10 +55,10 @@ def main():
         u = (np.arange(start, start + n, dtype=np.uint64) * a.stride).astype(np.uint32)
         x = u.view(np.float32)
         partner = ((u * np.uint32(2654435761)) ^ np.uint32(0x9E3779B9)).view(np.float32)  # atan2f's other argument: a bijective scramble
-        for fn in range(6):
+        for fn in range(7):
             y = partner if fn == 5 else None
             want = oracle_parallel(pool, a.workers, fn, x, y)
-            got = yk.device_math(ctx, fn, x, y)
+            got = yk.device_math(ctx, fn, x, y) if fn < 6 else want
             ok = same(got, want)
             dev_bad[fn] += int((~ok).sum())
             if not ok.all() and fn not in first:
@@ -71,8 +71,9 @@ def main():
         print(f"  {start + n:>11d} / {total} arguments, {time.time() - t0:6.0f} s, device differs {sum(dev_bad)}, host libm differs {sum(host_bad)}", flush=True)
     lines = [f"# device yk_libm.h vs oracle/olibm.h vs this host's libm ({os.confstr('CS_GNU_LIBC_VERSION')}), stride {a.stride}; NaNs as a class",
              f"# {time.time() - t0:.0f} s with {a.workers} host threads"]
-    for fn in range(6):
-        lines.append(f"{NAMES[fn]:7s} {count[fn]:>11d} arguments: device != oracle on {dev_bad[fn]}, oracle != platform libm on {host_bad[fn]}"
+    for fn in range(7):
+        dev = f"device != oracle on {dev_bad[fn]}" if fn < 6 else "(no device instance in use)"
+        lines.append(f"{NAMES[fn]:7s} {count[fn]:>11d} arguments: {dev}, oracle != platform libm on {host_bad[fn]}"
                      + (f"  first {first[fn]}" if fn in first else ""))
     print("\n".join(lines))
     if a.out:

@@ -354,6 +354,38 @@ YK_HD float gl_tanf(float x) {
     return gl_kernel_tanf(y0, y1, 1 - ((n & 1) << 1));
 }
 
+// expf (e_expf.c, the `__expf_fma` build; host side only — the pbrt loader's CIE fits): 2^(k/32) from a table, a cubic in binary64
+YK_HD unsigned long long gl_exp2f_entry(unsigned i) {
+    const unsigned long long tab[32] = {
+    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b, 0x3fef54873168b9aa, 0x3fef387a6e756238, 0x3fef1e9df51fdee1,
+    0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d, 0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429, 0x3feea47eb03a5585,
+    0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74, 0x3feea11473eb0187, 0x3feea589994cce13, 0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d,
+    0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f, 0x3fefa4afa2a490da, 0x3fefd0765b6e4540};
+    return tab[i & 31u];
+}
+YK_HD float gl_expf(float x) {
+    const unsigned ix = gl_to_bits(x), abstop = (ix >> 20) & 0x7ffu;
+    const double xd = (double)x;
+    if (abstop >= 0x42bu) {
+        if (ix == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8u) return x + x;
+        if (x > 0x1.62e42ep6f) return 0x1p97f * 0x1p97f;
+        if (x < -0x1.9fe368p6f) return 0x1p-95f * 0x1p-95f;
+        if (x < -0x1.9d1d9ep6f) return 0x1.4p-75f * 0x1.4p-75f;
+    }
+    const double shift = 0x1.8p+52, inv_ln2n = 0x1.71547652b82fep+5;
+    double kd = fma(inv_ln2n, xd, shift);
+    const unsigned long long ki = __builtin_bit_cast(unsigned long long, kd);
+    kd -= shift;
+    const double r = fma(inv_ln2n, xd, -kd);
+    const double s = __builtin_bit_cast(double, gl_exp2f_entry((unsigned)ki) + (ki << 47));
+    const double z = fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
+    const double r2 = r * r;
+    double y = fma(0x1.62e42ff0c52d6p-6, r, 1.0);
+    y = fma(z, r2, y);
+    return (float)(y * s);
+}
+
 YK_HD float det_tanf(float xf) {
 #if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)  // timing builds only: the hardware approximations instead
     return __tanf(xf);
@@ -371,5 +403,7 @@ YK_HD float det_logf(float xf) {
 YK_HD float det_atan2f(float yf, float xf) { return gl_atan2f(yf, xf); }
 
 YK_HD float det_acosf(float xf) { return gl_acosf(xf); }
+
+YK_HD float det_expf(float xf) { return gl_expf(xf); }
 
 }  // namespace yk

@@ -521,8 +521,8 @@ struct ParamSet {
     }
 };
 
-// pbrt/cie.rs (Wyman, Sloan, Shirley fits) — exp evaluated in f64 and rounded once
-float expf_once(float x) { return (float)std::exp((double)x); }
+// pbrt/cie.rs (Wyman, Sloan, Shirley fits) — f32::exp = glibc's expf, restated in yk_libm.h
+float expf_once(float x) { return yk::det_expf(x); }
 float x_fit_1931(float l) {
     float t1 = (l - 442.0f) * (l < 442.0f ? 0.0624f : 0.0374f);
     float t2 = (l - 599.8f) * (l < 599.8f ? 0.0264f : 0.0323f);
