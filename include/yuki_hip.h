@@ -504,6 +504,38 @@ yk_status yk_dist_create(yk_context* ctx, const uint8_t id[YK_DIST_ID_BYTES], ui
 void yk_dist_destroy(yk_dist* dist);
 yk_status yk_dist_gather(yk_dist* dist, const void* d_send, void* d_recv, size_t count, void* stream);
 
+/* ---- many render workers, one device ---------------------------------------------------------------------------
+ * The reference renders with num_cpus - 1 worker threads, each calling Integrator::render for ONE tile at a time
+ * (render_manager.rs:78-97, render_worker.rs:205-256).  yk_combiner_render_tile is that call for such a thread: it blocks
+ * until its tile is rendered, and the calls that are waiting at the same time are merged into one yk_render_tiles
+ * submission (the first waiter leads it, the others follow) on one of the combiner's contexts ("lanes": up to
+ * n_contexts submissions in flight; all on one device, each context once).  Every caller receives exactly the
+ * pixels a single-tile call returns.  max_tiles: most tiles per submission (0 = 64); linger_us: how long a caller
+ * that finds itself alone waits for company before it submits.
+ *   accumulating_sample < 0: Integrator::render(accumulating = false) — all samples of the pixel, the mean stored;
+ *   otherwise accumulating = true with FilmTile.sample = accumulating_sample (one sample, raw value).
+ *   Only calls for the same scene, camera, sampler, integrator and mode share a submission.
+ *   stats (may be NULL): times are the submission's; rays / shadow_rays / samples are the submission's counts shared
+ *   out by tile area with the remainder to the leading call — exact in sum over the callers, which is how the
+ *   reference uses them (render_manager.rs:277-281).
+ *   cancel: polled by the calling thread itself about every 100 us while it waits (the reference's predicate consumes
+ *   a channel message, render_worker.rs:240-249, so it must fire in its own worker).  Fired while the tile is still
+ *   queued: the call returns YK_ERR_CANCELLED at once.  Fired while the tile is part of a running submission: that
+ *   submission is interrupted; callers whose predicate has fired return YK_ERR_CANCELLED, the other callers' tiles
+ *   are queued again — nobody is handed pixels of an interrupted job. */
+typedef struct yk_combiner yk_combiner;
+typedef struct yk_combiner_info {
+    uint64_t submissions, tiles, requeued; /* submissions made, tiles rendered through them, tiles queued again after an interruption */
+    uint32_t largest_submission, lanes;
+} yk_combiner_info;
+yk_status yk_combiner_create(yk_context* const* contexts, uint32_t n_contexts, uint32_t max_tiles, uint32_t linger_us, yk_combiner** out);
+void yk_combiner_destroy(yk_combiner* combiner); /* no call may be waiting in it */
+yk_status yk_combiner_render_tile(yk_combiner* combiner, const yk_scene* scene, const yk_camera* camera, const yk_sampler_desc* sampler,
+                                  const yk_integrator_desc* integrator, const yk_tile* tile, int32_t accumulating_sample, float* tile_pixels,
+                                  yk_render_stats* stats, yk_cancel_fn cancel, void* user);
+yk_status yk_combiner_get_info(const yk_combiner* combiner, yk_combiner_info* out);
+yk_status yk_combiner_last_error(const yk_combiner* combiner, char* buf, size_t cap);
+
 /* ---- scene input -------------------------------------------
  * The reference's loaders, host-only (no device needed): they produce the flattened
  * scene description yk_scene_create consumes plus the camera and film settings the

@@ -216,6 +216,42 @@ class Integrator {
     yk_integrator_desc desc_;
 };
 
+// The render workers' shared door to the device (render_manager.rs:78-97: num_cpus - 1 threads, each calling Integrator::render for
+// one tile): calls that wait at the same time share a submission on one of the lanes' contexts (yk_combiner in yuki_hip.h).
+class Combiner {
+   public:
+    explicit Combiner(const std::vector<Context*>& lanes, uint32_t max_tiles = 0, uint32_t linger_us = 100) {
+        std::vector<yk_context*> h;
+        for (Context* c : lanes) h.push_back(c->handle());
+        check(yk_combiner_create(h.data(), (uint32_t)h.size(), max_tiles, linger_us, &c_));
+    }
+    ~Combiner() { yk_combiner_destroy(c_); }
+    Combiner(const Combiner&) = delete;
+    Combiner& operator=(const Combiner&) = delete;
+    // Integrator::render for one FilmTile from a worker thread; accumulating_sample < 0: all samples of the pixel, the mean stored.
+    // Returns the ray count (the submission's, shared out by tile area: exact in sum).  Throws Error(YK_ERR_CANCELLED) when the
+    // caller's own predicate fired.
+    size_t render(const Scene& scene, const Camera& camera, const yk_sampler_desc& sampler, const yk_integrator_desc& integrator, const FilmTile& tile,
+                  float* tile_pixels, int32_t accumulating_sample = -1, yk_cancel_fn cancel = nullptr, void* user = nullptr) {
+        yk_render_stats st{};
+        const yk_status rc = yk_combiner_render_tile(c_, scene.handle(), &camera.matrices, &sampler, &integrator, &tile, accumulating_sample, tile_pixels, &st, cancel, user);
+        if (rc != YK_OK) {
+            char buf[512] = {0};
+            yk_combiner_last_error(c_, buf, sizeof buf);
+            throw Error(rc, buf);
+        }
+        return (size_t)st.rays;
+    }
+    yk_combiner_info info() const {
+        yk_combiner_info i{};
+        check(yk_combiner_get_info(c_, &i));
+        return i;
+    }
+
+   private:
+    yk_combiner* c_ = nullptr;
+};
+
 // All GPUs of the process behind one object — RenderManager's role for GPU workers
 // (renderer/render_manager.rs:78-97: one worker per device; :206-210: interleaved tiles;
 // film.rs:210-282: the write-back).  devices[0] assembles the film.

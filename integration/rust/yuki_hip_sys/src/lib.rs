@@ -192,6 +192,16 @@ pub struct yk_scene_info {
 
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
+pub struct yk_combiner_info {
+    pub submissions: u64,
+    pub tiles: u64,
+    pub requeued: u64,
+    pub largest_submission: u32,
+    pub lanes: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
 pub struct yk_render_stats {
     pub rays: u64,
     pub shadow_rays: u64,
@@ -216,6 +226,7 @@ pub enum yk_multi {}
 pub enum yk_multi_scene {}
 pub enum yk_multi_film {}
 pub enum yk_dist {}
+pub enum yk_combiner {}
 pub type yk_cancel_fn = Option<unsafe extern "C" fn(user: *mut c_void) -> c_int>;
 
 extern "C" {
@@ -249,6 +260,11 @@ extern "C" {
     pub fn yk_render_tiles_accumulating_passes(ctx: *mut yk_context, scene: *const yk_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, tiles: *const yk_tile, tile_samples: *const u16, n_tiles: usize, n_passes: u32, out_rgb: *mut f32, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
     pub fn yk_render_tile_list_samples_device(ctx: *mut yk_context, scene: *const yk_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, list: *const yk_tile_list, first_sample: u32, n_passes: u32, d_out_rgb: *mut c_void, stream: *mut c_void, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
     pub fn yk_context_interrupt(ctx: *mut yk_context) -> yk_status;
+    pub fn yk_combiner_create(contexts: *const *mut yk_context, n_contexts: u32, max_tiles: u32, linger_us: u32, out: *mut *mut yk_combiner) -> yk_status;
+    pub fn yk_combiner_destroy(combiner: *mut yk_combiner);
+    pub fn yk_combiner_render_tile(combiner: *mut yk_combiner, scene: *const yk_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, tile: *const yk_tile, accumulating_sample: i32, tile_pixels: *mut f32, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
+    pub fn yk_combiner_get_info(combiner: *const yk_combiner, out: *mut yk_combiner_info) -> yk_status;
+    pub fn yk_combiner_last_error(combiner: *const yk_combiner, buf: *mut c_char, cap: usize) -> yk_status;
     pub fn yk_render_tile_list_passes_device(ctx: *mut yk_context, scene: *const yk_scene, camera: *const yk_camera, sampler: *const yk_sampler_desc, integrator: *const yk_integrator_desc, list: *const yk_tile_list, n_passes: u32, d_out_rgb: *mut c_void, stream: *mut c_void, stats: *mut yk_render_stats, cancel: yk_cancel_fn, user: *mut c_void) -> yk_status;
     pub fn yk_film_accumulate_tile_list_passes_device(ctx: *mut yk_context, list: *const yk_tile_list, d_passes_rgb: *const c_void, n_passes: u32, res_x: u16, res_y: u16, d_film_rgb: *mut c_void, stream: *mut c_void) -> yk_status;
     pub fn yk_write_exr(path: *const c_char, width: u32, height: u32, rgb: *const f32) -> yk_status;
@@ -290,6 +306,13 @@ extern "C" {
 }
 
 /// `yk_last_error` as a `String` (empty when none).
+pub fn combiner_last_error(combiner: *const yk_combiner) -> String {
+    let mut buf = vec![0u8; 512];
+    unsafe { yk_combiner_last_error(combiner, buf.as_mut_ptr() as *mut c_char, buf.len()) };
+    let n = buf.iter().position(|&b| b == 0).unwrap_or(buf.len());
+    String::from_utf8_lossy(&buf[..n]).into_owned()
+}
+
 pub fn last_error(ctx: *const yk_context) -> String {
     let mut buf = vec![0u8; 512];
     unsafe { yk_last_error(ctx, buf.as_mut_ptr() as *mut c_char, buf.len()) };

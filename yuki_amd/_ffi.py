@@ -64,6 +64,10 @@ class RenderStats(C.Structure):
     ]
 
 
+class CombinerInfo(C.Structure):
+    _fields_ = [("submissions", C.c_uint64), ("tiles", C.c_uint64), ("requeued", C.c_uint64), ("largest_submission", C.c_uint32), ("lanes", C.c_uint32)]
+
+
 CANCEL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 # name -> (restype, argtypes); every symbol include/yuki_hip.h declares
@@ -129,6 +133,11 @@ SYMBOLS = {
     "yk_multi_film_clear": (C.c_int, [vp, vp]),
     "yk_multi_interrupt": (C.c_int, [vp]),
     "yk_context_interrupt": (C.c_int, [vp]),
+    "yk_combiner_create": (C.c_int, [C.POINTER(vp), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+    "yk_combiner_destroy": (None, [vp]),
+    "yk_combiner_render_tile": (C.c_int, [vp, vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.IntegratorDesc), C.POINTER(abi.Tile), C.c_int32, vp, C.POINTER(RenderStats), vp, vp]),
+    "yk_combiner_get_info": (C.c_int, [vp, C.POINTER(CombinerInfo)]),
+    "yk_combiner_last_error": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
     "yk_multi_destroy": (None, [vp]),
     "yk_multi_device_count": (C.c_uint32, [vp]),
     "yk_multi_context": (vp, [vp, C.c_uint32]),

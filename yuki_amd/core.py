@@ -475,6 +475,55 @@ class Dist:
             self.h = None
 
 
+# --------------------------------------------------------------------------- many workers, one device
+class Combiner:
+    """yk_combiner: Integrator::render called per tile from many worker threads (render_manager.rs:78-97), merged into shared
+    submissions on `contexts` (one lane each).  `render` is what a worker thread calls; it blocks until its tile is done."""
+
+    def __init__(self, contexts, max_tiles=0, linger_us=100):
+        self.contexts = list(contexts)
+        arr = (C.c_void_p * len(self.contexts))(*[c.h for c in self.contexts])
+        h = C.c_void_p()
+        check(lib().yk_combiner_create(arr, len(self.contexts), max_tiles, linger_us, C.byref(h)))
+        self.h = h
+
+    def _error(self, status):
+        buf = C.create_string_buffer(512)
+        lib().yk_combiner_last_error(self.h, buf, 512)
+        return YukiError(status, buf.value.decode(errors="replace"))
+
+    def render(self, integrator, scene, camera, sampler, tile, accumulating=False, cancel=None):
+        """(tile_pixels[h*w,3], RenderStats) — integrators/mod.rs:120-185 for one FilmTile."""
+        t = tile.as_struct() if isinstance(tile, FilmTile) else abi.Tile(*[int(v) for v in tile])
+        w, h = t.x1 - t.x0, t.y1 - t.y0
+        px = np.zeros((max(w, 0) * max(h, 0), 3), dtype=np.float32)
+        stats = RenderStats()
+        desc = integrator.desc if isinstance(integrator, Integrator) else integrator
+        sample = (tile.sample if isinstance(tile, FilmTile) else 0) if accumulating else -1
+        cb = _ffi.CANCEL_FN(lambda _u: 1 if cancel() else 0) if cancel else None
+        st = lib().yk_combiner_render_tile(self.h, scene.h, C.byref(camera.matrices), C.byref(sampler), C.byref(desc), C.byref(t), sample, _p(px), C.byref(stats),
+                                           C.cast(cb, C.c_void_p) if cb else None, None)
+        if st != 0:
+            raise self._error(st)
+        return px, stats
+
+    def info(self):
+        out = _ffi.CombinerInfo()
+        check(lib().yk_combiner_get_info(self.h, C.byref(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().yk_combiner_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # --------------------------------------------------------------------------- integrators
 class Integrator:
     """trait Integrator (integrators/mod.rs:92-186) over the HIP wavefront."""
