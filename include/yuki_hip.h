@@ -389,7 +389,8 @@ yk_status yk_camera_rays(yk_context* ctx, const yk_camera* camera, const yk_samp
  * 6 sqrt, 7 a/b, 8 f64-sqrt helper, 9 / 10 f32::min / max; 11..27 work on packed triples (n = 3 x count):
  * 11 Vec3::dot, 12 cross, 13 len, 14 normalized, 15 max_dimension, 16 abs, 17 Normal::dot_v, 18 the kx/ky/kz
  * permutation of Triangle::intersect, 19 / 20 Vec3::min / max, 21 Normal::faceforward_v, 22 a + b, 23 a - b,
- * 24 a * b.x, 25 a / b.x, 26 -a, 27 len_sqr (result in out[3k..3k+2]) */
+ * 24 a * b.x, 25 a / b.x, 26 -a, 27 len_sqr (result in out[3k..3k+2]); scalar again: 28 / 29 the sine / cosine of the
+ * shared-reduction pair the shading code calls (the same bits as fn 0 / 1) */
 yk_status yk_device_math(yk_context* ctx, int fn, size_t n, const float* a, const float* b, float* out);
 /* Bsdf::f and Bsdf::sample_f on the device for n (wo, wi|u) pairs against one material */
 yk_status yk_bsdf_eval(yk_context* ctx, const yk_material_desc* material, size_t n, const float* n_geom,

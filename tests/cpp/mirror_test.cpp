@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "yuki_hip.hpp"
@@ -110,6 +112,26 @@ int main(int argc, char** argv) {
         bool eq = true;
         for (size_t k = 0; k < acc.size(); ++k) eq = eq && (acc[k] / 4.0f == film[k]);
         std::printf("accumulate_matches_plain=%d\n", eq ? 1 : 0);
+    }
+    // the reference's render workers as they are (render_manager.rs:78-97): six threads, each rendering one tile at a time through the
+    // combiner; every tile equals its slab of the batched film and the ray counts add up
+    {
+        Context lane2(0);
+        Combiner comb({&ctx, &lane2}, 0, 200);
+        std::vector<float> out(film.size(), -1.0f);
+        std::vector<size_t> offs(tiles.size() + 1, 0);
+        for (size_t t = 0; t < tiles.size(); ++t) offs[t + 1] = offs[t] + (size_t)(tiles[t].x1 - tiles[t].x0) * (tiles[t].y1 - tiles[t].y0);
+        std::atomic<size_t> next{0}, total_rays{0};
+        std::vector<std::thread> workers;
+        for (int k = 0; k < 6; ++k)
+            workers.emplace_back([&] {
+                for (size_t t = next++; t < tiles.size(); t = next++)
+                    total_rays += comb.render(scene, cam, smp, IntegratorType::Path(PathParams{6, false, 0.0f}), tiles[t], out.data() + offs[t] * 3);
+            });
+        for (auto& w : workers) w.join();
+        yk_combiner_info ci = comb.info();
+        std::printf("combiner_matches_batch=%d combiner_rays_match=%d combiner_merged=%d\n", std::memcmp(out.data(), film.data(), film.size() * 4) == 0 ? 1 : 0,
+                    total_rays.load() == st.rays ? 1 : 0, (ci.tiles == tiles.size() && ci.submissions < ci.tiles) ? 1 : 0);
     }
     // the GPUs of the process behind one object (here: device 0, the RCCL exchange looped back to itself): the film
     // equals Film::update_tile of the batched render above

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _build(tmp_path):
     exe = str(tmp_path / "mirror_test")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "mirror_test.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "mirror_test.cpp"),
                            "-o", exe, "-L", os.path.join(ROOT, "yuki_amd"), "-lyuki_hip", "-Wl,-rpath," + os.path.join(ROOT, "yuki_amd")])
     return exe
 
@@ -57,6 +57,8 @@ def test_cxx_mirror_renders(tmp_path):
     assert kv["tile_matches_batch"] == "1" and int(kv["tile_rays"]) > 0
     assert kv["bad_tile"] == "status1"
     assert kv["accumulate_matches_plain"] == "1"
+    # six worker threads through the Combiner: every tile is its slab of the batched film
+    assert kv["combiner_matches_batch"] == "1" and kv["combiner_rays_match"] == "1" and kv["combiner_merged"] == "1"
     assert kv["node_rays_match"] == "1" and kv["node_film_matches"] == "1" and kv["node_devices"] == "1" and kv["node_dup"] == "status1"
     # three virtual ranks on one device, the accumulating film over them, the device-free deal
     assert kv["virtual_ranks_match"] == "1" and kv["virtual_ranks_accumulate"] == "1" and kv["deal_covers_film"] == "1"

@@ -33,6 +33,10 @@ def test_device_libm_matches_oracle_bit_exact(ctx, yk, oracle):
         want = oracle.libm_array(fn, x)
         ok = _same_or_both_nan(got, want)
         assert ok.all(), (name, int((~ok).sum()), x[~ok][:6], got[~ok][:6], want[~ok][:6])
+    # the pair the shading code calls (one reduction, both results): the same bits as the two functions
+    for fn, ofn in ((28, 0), (29, 1)):
+        ok = _same_or_both_nan(yk.device_math(ctx, fn, x), oracle.libm_array(ofn, x))
+        assert ok.all(), ("sincos pair", fn, int((~ok).sum()), x[~ok][:6])
     y = np.concatenate([rng.permutation(strided), rng.uniform(-3, 3, 220000).astype(np.float32), np.array([0.0, -0.0, 1.0, -1.0, 0.0, 1e-30, -0.0, 2.0, 0.0, 0.0], np.float32)])
     got = yk.device_math(ctx, 5, y, x)
     want = oracle.libm_array(5, y, x)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The device instance of yuki_amd/csrc/yk_libm.h against oracle/olibm.h for ALL 2^32 binary32 arguments of
 sinf, cosf, tanf, logf, acosf (and atan2f: every argument as y against x = rotated copy, and as x against the same),
-plus the oracle against this host's platform libm on the same sweep (the `hostlibm` build of the oracle).
+plus the oracle against this host's platform libm on the same sweep (the `hostlibm` build of the oracle), and the device's f32
+sqrt and division against IEEE (numpy on the host) on the same arguments.
 GPU box:  python tools/gpu_libm_exhaustive.py [--stride 1] [--out gpurun_out/device_libm_exhaustive.txt]
 """
 import argparse
@@ -47,6 +48,7 @@ def main():
     dev_bad = [0] * 7
     host_bad = [0] * 7
     count = [0] * 7
+    sqrt_bad = rcp_bad = pair_bad = 0
     first = {}
     t0 = time.time()
     total = (1 << 32) // a.stride
@@ -68,6 +70,13 @@ def main():
                 host = oracle_parallel(pool, a.workers, fn, x, y)
             host_bad[fn] += int((~same(host, want)).sum())
             count[fn] += n
+        # det_sincosf, the shared-reduction pair of the shading code, against the oracle's sinf / cosf
+        pair_bad += int((~same(yk.device_math(ctx, 28, x), oracle_parallel(pool, a.workers, 0, x, None))).sum())
+        pair_bad += int((~same(yk.device_math(ctx, 29, x), oracle_parallel(pool, a.workers, 1, x, None))).sum())
+        # the two IEEE operations everything else leans on: f32 sqrt and division on gfx950 against the host's (correctly rounded)
+        with np.errstate(all="ignore"):
+            sqrt_bad += int((~same(yk.device_math(ctx, 6, x), np.sqrt(x))).sum())
+            rcp_bad += int((~same(yk.device_math(ctx, 7, partner, x), partner / x)).sum())
         print(f"  {start + n:>11d} / {total} arguments, {time.time() - t0:6.0f} s, device differs {sum(dev_bad)}, host libm differs {sum(host_bad)}", flush=True)
     lines = [f"# device yk_libm.h vs oracle/olibm.h vs this host's libm ({os.confstr('CS_GNU_LIBC_VERSION')}), stride {a.stride}; NaNs as a class",
              f"# {time.time() - t0:.0f} s with {a.workers} host threads"]
@@ -75,12 +84,15 @@ def main():
         dev = f"device != oracle on {dev_bad[fn]}" if fn < 6 else "(no device instance in use)"
         lines.append(f"{NAMES[fn]:7s} {count[fn]:>11d} arguments: {dev}, oracle != platform libm on {host_bad[fn]}"
                      + (f"  first {first[fn]}" if fn in first else ""))
+    lines.append(f"sincos pair (one reduction, both results) {count[0]:>11d} arguments: device != oracle's sinf / cosf on {pair_bad}")
+    lines.append(f"sqrt    {count[0]:>11d} arguments: device f32 sqrt != IEEE on {sqrt_bad}")
+    lines.append(f"div     {count[0]:>11d} pairs (scrambled partner / argument): device f32 division != IEEE on {rcp_bad}")
     print("\n".join(lines))
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
         with open(a.out, "w") as f:
             f.write("\n".join(lines) + "\n")
-    return 1 if sum(dev_bad) or sum(host_bad) else 0
+    return 1 if sum(dev_bad) or sum(host_bad) or sqrt_bad or rcp_bad or pair_bad else 0
 
 
 if __name__ == "__main__":

@@ -30,6 +30,8 @@ static inline float r_acos(float x) { return yk::det_acosf(x); }
 static inline float r_exp(float x) { return yk::det_expf(x); }
 static inline float r_atan(float x) { return yk::gl_atanf(x); }
 static inline float r_atan2(float y, float x) { return yk::det_atan2f(y, x); }
+#define HAVE_PAIR 1
+static inline void r_pair(float x, float& s, float& c) { yk::det_sincosf(x, s, c); }
 #else
 #include "olibm.h"
 #define WHAT "oracle/olibm.h"
@@ -59,8 +61,8 @@ int main(int argc, char** argv) {
     const unsigned stride = argc > 1 ? (unsigned)std::atoi(argv[1]) : 1u;
     const unsigned mask = argc > 2 ? (unsigned)std::strtoul(argv[2], nullptr, 0) : 0xffffffffu;  // bit per row of the table below
     const unsigned T = std::max(1u, std::thread::hardware_concurrency());
-    enum { SIN, COS, TAN, LOG, EXP, ACOS, ATAN, ATAN2_SPECIAL, ATAN2_RANDOM, NF };
-    const char* names[NF] = {"sinf", "cosf", "tanf", "logf", "expf", "acosf", "atanf", "atan2f(special partners)", "atan2f(random pairs)"};
+    enum { SIN, COS, TAN, LOG, EXP, ACOS, ATAN, ATAN2_SPECIAL, ATAN2_RANDOM, PAIR, NF };
+    const char* names[NF] = {"sinf", "cosf", "tanf", "logf", "expf", "acosf", "atanf", "atan2f(special partners)", "atan2f(random pairs)", "sincos pair (shared reduction)"};
     std::atomic<uint64_t> bad[NF], done[NF];
     for (int i = 0; i < NF; ++i) bad[i] = 0, done[i] = 0;
     static const uint32_t special[24] = {0x00000000u, 0x80000000u, 0x3f800000u, 0xbf800000u, 0x7f800000u, 0xff800000u, 0x7fc00000u, 0x00000001u,
@@ -100,6 +102,17 @@ int main(int argc, char** argv) {
                 ONE(ACOS, ::acosf, r_acos)
                 ONE(ATAN, ::atanf, r_atan)
 #undef ONE
+#ifdef HAVE_PAIR
+                if (mask & (1u << PAIR)) {  // the pair the shading code calls: both results against the platform's sinf and cosf
+                    float ps, pc;
+                    r_pair(x, ps, pc);
+                    a = ::sinf(x);
+                    if (!same(a, ps)) report(PAIR, u, 0, a, ps);
+                    a = ::cosf(x);
+                    if (!same(a, pc)) report(PAIR, u, 1, a, pc);
+                    ++n[PAIR];
+                }
+#endif
                 const uint32_t sp = special[(i / stride) % 24];  // every argument meets every partner once per 24 strides; all of them when stride == 1 below
                 for (int k = 0; (mask & (1u << ATAN2_SPECIAL)) && k < (stride == 1 ? 24 : 1); ++k) {
                     const uint32_t p = stride == 1 ? special[k] : sp;

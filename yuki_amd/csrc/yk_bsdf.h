@@ -48,8 +48,10 @@ YK_HD void concentric_sample_disk(float ux, float uy, float& dx, float& dy) {
         theta = YK_FRAC_PI_2 - YK_FRAC_PI_4 * (ox / oy);
         r = oy;
     }
-    dx = det_cosf(theta) * r;
-    dy = det_sinf(theta) * r;
+    float sn, cs;
+    det_sincosf(theta, sn, cs);  // sinf(theta), cosf(theta) with the argument reduced once: the same bits as two calls
+    dx = cs * r;
+    dy = sn * r;
 }
 // sampling/mod.rs:62-66
 YK_HD V3 cosine_sample_hemisphere(float ux, float uy) {
@@ -154,7 +156,9 @@ YK_HD V3 tr_sample_wh(float alpha, V3 wo, float u0, float u1) {
     float cos_t = 1.0f / sqrtf(1.0f + tan_theta_2);
     float phi = 2.0f * YK_PI * u1;
     float sin_t = sqrtf(rmax(1.0f - cos_t * cos_t, 0.0f));
-    V3 wh = V3{sin_t * det_cosf(phi), sin_t * det_sinf(phi), cos_t};
+    float sn, cs;
+    det_sincosf(phi, sn, cs);
+    V3 wh = V3{sin_t * cs, sin_t * sn, cos_t};
     return same_hemisphere(wo, wh) ? wh : -wh;
 }
 

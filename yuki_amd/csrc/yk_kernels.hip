@@ -602,7 +602,7 @@ __global__ void k_debug_shade(DevScene sc, uint32_t integrator, PathBuffers cur,
 __global__ void k_device_math(int fn, size_t n, const float* a, const float* b, float* out) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (fn >= 11) {  // vector functions of yk_math.h / yk_geom.h on triples: a, b = n/3 packed V3, thread 3k handles triple k
+    if (fn >= 11 && fn <= 27) {  // vector functions of yk_math.h / yk_geom.h on triples: a, b = n/3 packed V3, thread 3k handles triple k
         if (i % 3) return;
         V3 va = V3{a[i], a[i + 1], a[i + 2]}, vb = b ? V3{b[i], b[i + 1], b[i + 2]} : V3{0.0f, 0.0f, 0.0f};
         V3 r = V3{0.0f, 0.0f, 0.0f};
@@ -649,6 +649,13 @@ __global__ void k_device_math(int fn, size_t n, const float* a, const float* b, 
         case 8: r = (float)sqrt((double)x); break;
         case 9: r = rmin(x, y); break;
         case 10: r = rmax(x, y); break;
+        case 28:  // det_sincosf (the reduction shared by both results): its sine ...
+        case 29: {  // ... and its cosine
+            float sn, cs;
+            det_sincosf(x, sn, cs);
+            r = fn == 28 ? sn : cs;
+            break;
+        }
         default: r = 0.0f;
     }
     out[i] = r;

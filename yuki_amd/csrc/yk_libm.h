@@ -112,11 +112,50 @@ YK_HD float gl_sincosf(float y, int want_cos) {
     return use_cos ? gl_poly_cos(x * x, neg) : gl_poly_sin(x * s, x * x);
 }
 
+// sinf(y) and cosf(y) of the same argument with the reduction done once: the two functions reduce y identically (same quadrant n,
+// same remainder), so sharing it changes no bit — what differs per function is only which polynomial serves which quadrant.
+// Below 120 there is ONE path for all lanes: glibc's shortcut for |y| < pi/4 is its general path with n = 0 (reduce_fast then
+// returns y itself: fma(-0, pi/2, y)), so taking the general path there gives the same bits without the lanes of a wave parting
+// ways at pi/4 — the disk sample's theta straddles it.  |y| < 2^-12 keeps glibc's exact answers (y and 1).
+YK_HD void gl_sincosf_pair(float y, float& sin_out, float& cos_out) {
+    const unsigned xi = __builtin_bit_cast(unsigned, y), top = (xi >> 20) & 0x7ffu;
+    double x = (double)y;
+    int n, sign = 0;
+    if (top < 0x42fu) {
+        x = gl_reduce_fast(x, n);
+    } else if (top < 0x7f8u) {
+        sign = (int)(xi >> 31);
+        x = gl_reduce_large(xi, n);
+    } else {
+        sin_out = cos_out = y - y;
+        return;
+    }
+    const int q = (n + sign) & 3;
+    const double s = (q == 1 || q == 2) ? -1.0 : 1.0;
+    const bool neg = ((n + sign) & 2) != 0;
+    const double x2 = x * x;
+    const float by_sin = gl_poly_sin(x * s, x2), by_cos = gl_poly_cos(x2, neg);
+    // sinf takes the cosine polynomial in odd quadrants; cosf is sinf one quadrant on (sinf_poly(.., n ^ 1)); signs and table follow n + sign in both
+    const bool tiny = top < 0x398u;
+    sin_out = tiny ? y : ((n & 1) ? by_cos : by_sin);
+    cos_out = tiny ? 1.0f : ((n & 1) ? by_sin : by_cos);
+}
+
 YK_HD float det_sinf(float xf) {
 #if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)  // timing builds only: the hardware approximations instead
     return __sinf(xf);
 #endif
     return gl_sincosf(xf, 0);
+}
+
+// sin and cos of one angle (the disk sample's theta, the microfacet normal's phi)
+YK_HD void det_sincosf(float xf, float& s, float& c) {
+#if defined(YK_ABLATE_LIBM) && defined(__HIP_DEVICE_COMPILE__)
+    s = __sinf(xf);
+    c = __cosf(xf);
+    return;
+#endif
+    gl_sincosf_pair(xf, s, c);
 }
 
 YK_HD float det_cosf(float xf) {
