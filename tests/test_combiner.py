@@ -132,8 +132,8 @@ def test_combiner_interruption_reaches_only_its_caller(yk):
     """One worker's predicate fires while its tile is inside a running submission (a long job: 4096 spp): that call returns
     CANCELLED; the other workers' tiles are queued again and come back complete and identical to a plain render."""
     sd = scenes.by_name("city-small")
-    fs = yk.FilmSettings(res=(64, 64))
-    tiles = yk.film_tiles(fs)
+    fs = yk.FilmSettings(res=(128, 64))
+    tiles = yk.film_tiles(fs)  # 32 tiles x 256 pixels x 4096 spp: ~100 ms, three times what the assertion below needs
     smp = yk.SamplerType.Stratified((64, 64), True, SEED)
     integ = yk.IntegratorType.Path(yk.PathParams(max_depth=8))
     ctx = yk.Context(0)

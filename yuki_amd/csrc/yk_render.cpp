@@ -226,14 +226,20 @@ void run_bounces(yk_context* ctx, WorkSet& ws, hipStream_t st, const yk_scene* s
 // ------------------------------------------------------------------ interruption (yk_device.h, CancelRef)
 // Raise the host's word: every traversal launch's relay wave sees it at its next claim (yk_device.h, CancelRef) and raises the
 // device word that every later launch reads when it starts.
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static const bool g_debug_cancel = std::getenv("YK_DEBUG_CANCEL") != nullptr;
+
 static void raise_cancel(yk_context* ctx, bool from_render_thread = true) {
     if (!ctx->cancel_host) return;
+    const double t0 = g_debug_cancel ? now_ms() : 0.0;
     ctx->cancel_raised.store(true, std::memory_order_release);
     __atomic_store_n(ctx->cancel_host, 1u, __ATOMIC_RELEASE);
     // ... and the device word directly (a copy engine's job: it does not queue behind the kernels): k_shade looks at this one only
     if (from_render_thread && !ctx->cancel_stream && hipStreamCreateWithFlags(&ctx->cancel_stream, hipStreamNonBlocking) != hipSuccess) ctx->cancel_stream = nullptr;
+    const double t1 = g_debug_cancel ? now_ms() : 0.0;
     if (from_render_thread && ctx->cancel_stream && ctx->counters.p)
         (void)hipMemcpyAsync(error_block(ctx) + YK_CTRL_CANCELLED, ctx->cancel_host + 16, 4, hipMemcpyHostToDevice, ctx->cancel_stream);
+    if (g_debug_cancel) std::fprintf(stderr, "[yk cancel] raise: stream %.3f ms, copy enqueue %.3f ms\n", t1 - t0, now_ms() - t1);
 }
 
 // Called by a submission before it enqueues anything: if an earlier one was interrupted, whatever it still has on the
@@ -473,8 +479,16 @@ static yk_status render_tiles_impl(yk_context* ctx, const yk_scene* scene, const
                 fired = true;
             }
             if (fired) {  // what is already enqueued drains at once
+                const double t0 = g_debug_cancel ? now_ms() : 0.0;
                 (void)hipStreamSynchronize(st);
+                const double t1 = g_debug_cancel ? now_ms() : 0.0;
                 if (n_ws == 2) (void)hipStreamSynchronize(ctx->ws[1].stream);
+                if (g_debug_cancel) {
+                    unsigned words[4] = {0, 0, 0, 0};
+                    (void)hipMemcpy(words, error_block(ctx), sizeof words, hipMemcpyDeviceToHost);
+                    std::fprintf(stderr, "[yk cancel] drain: stream0 %.3f ms, stream1 %.3f ms, batch %llu of %llu, device word %u\n", t1 - t0, now_ms() - t1,
+                                 (unsigned long long)(w0 / batch), (unsigned long long)((work + batch - 1) / batch), words[YK_CTRL_CANCELLED]);
+                }
                 return fail(ctx, YK_ERR_CANCELLED, "cancelled by early_termination_predicate");
             }
             hipStream_t bs = n_ws == 2 ? ws.stream : st;
