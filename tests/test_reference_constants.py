@@ -112,3 +112,74 @@ def test_copper_tables_and_cie_fits_match_the_references_text():
     assert [abs(v) for v in got_py] == matrix
     b = cxx.index("rgb[0] = ")
     assert [np.float32(v) for v in re.findall(r"(\d\.\d+)f", cxx[b:cxx.index("measured copper")])] == matrix
+
+
+def test_pbrt_loader_defaults_match_the_references_text(tmp_path):
+    """Every `params.find_*("name", default)` of scene/pbrt/mod.rs: the default is read out of the reference's text and compared
+    with what both loaders produce for the BARE directive (no parameters given)."""
+    import re
+
+    from oracle import loaders as ol
+    from yuki_amd import abi, loaders
+
+    ref = open("/root/reference/yuki/src/scene/pbrt/mod.rs").read()
+    ref = re.sub(r"\s+", " ", ref)
+    found = []
+    for m in re.finditer(r'find_(f32|i32|bool|spectrum|point|string)\( ?"(\w+)", ?', ref):
+        depth, j = 1, m.end()
+        while depth:  # the default runs to the call's closing parenthesis
+            depth += {"(": 1, ")": -1}.get(ref[j], 0)
+            j += 1
+        found.append((m.group(1), m.group(2), ref[m.end():j - 1].strip().rstrip(",").strip()))
+    names = [n for _, n, _ in found]
+    # the order of appearance fixes which directive a repeated name ("L", "from", "roughness", "eta", "Kd") belongs to
+    assert names == ["fov", "xresolution", "yresolution", "L", "L", "from", "to", "I", "from", "radius", "filename", "filename",
+                     "Kr", "Kt", "eta", "Rs", "roughness", "Kd", "Kd", "sigma", "eta", "k", "roughness", "remaproughness"], names
+    d = [v for _, _, v in found]
+
+    def spectrum(text, variables={"default_l": "Spectrum::ones()", "default_i": "Spectrum::ones()"}):
+        text = variables.get(text, text)
+        if text == "Spectrum::ones()":
+            return (1.0, 1.0, 1.0)
+        m = re.fullmatch(r"Spectrum::new\(([\d.]+), ([\d.]+), ([\d.]+)\)", text)
+        return tuple(float(v) for v in m.groups())
+
+    def point(text, variables={"default_pos": "Point3::zeros()"}):
+        text = variables.get(text, text)
+        if text == "Point3::zeros()":
+            return (0.0, 0.0, 0.0)
+        return tuple(float(v) for v in re.fullmatch(r"Point3::new\(([\d.]+), ([\d.]+), ([\d.]+)\)", text).groups())
+
+    assert 'let default_l = Spectrum::ones();' in ref and 'let default_i = Spectrum::ones();' in ref and 'let default_pos = Point3::zeros();' in ref
+    p = str(tmp_path / "bare.pbrt")
+    with open(p, "w") as f:
+        f.write('Camera "perspective"\nFilm "image"\nWorldBegin\nLightSource "infinite"\nLightSource "distant"\nLightSource "point"\n'
+                'Material "glass"\nShape "sphere"\nMaterial "glossy"\nShape "sphere"\nMaterial "matte"\nShape "sphere"\nMaterial "metal"\nShape "sphere"\nWorldEnd\n')
+    want, wcam, wres = ol.load_pbrt(p)
+    got, cam, film = loaders.load_pbrt(p)
+    # both loaders agree on the file (the full comparison is tests/test_loaders.py's)
+    assert [bytes(x) for x in want.light_structs] == [bytes(x) for x in got.light_structs] and len(want.materials) == len(got.materials)
+    f32 = np.float32
+    assert f32(wcam["fov_degrees"]) == f32(d[0]) == f32(cam.fov_degrees) and wcam["fov_axis"] == abi.FOV_Y == cam.fov_axis  # FoV::Y(find_f32("fov", 45.0))
+    assert tuple(wres) == (int(d[1]), int(d[2])) == tuple(film.res)
+    assert tuple(f32(v) for v in want.background) == tuple(f32(v) for v in spectrum(d[3]))  # infinite: L
+    distant, pnt = got.light_structs[0], got.light_structs[1]
+    assert distant.kind == abi.LIGHT_DISTANT and tuple(distant.i) == spectrum(d[4])  # distant: L; direction (from - to).normalized()
+    frm, to = np.asarray(point(d[5]), f32), np.asarray(point(d[6]), f32)
+    w = frm - to
+    assert np.allclose(np.asarray(tuple(distant.p), f32), w / np.linalg.norm(w))  # a distant light keeps its direction in `p`
+    assert pnt.kind == abi.LIGHT_POINT and tuple(pnt.i) == spectrum(d[7]) and tuple(pnt.p) == point(d[8])
+    assert all(f32(s["radius"]) == f32(d[9]) for s in got.spheres) and len(got.spheres) == 4
+    assert d[10] == d[11] == '""'
+    glass = next(m for m in want.materials if m["kind"] == abi.MAT_GLASS)
+    assert tuple(glass["a"]) == spectrum(d[12]) and tuple(glass["b"]) == spectrum(d[13]) and f32(glass["c"]) == f32(d[14])
+    glossy = next(m for m in want.materials if m["kind"] == abi.MAT_GLOSSY)
+    assert tuple(f32(v) for v in glossy["a"]) == tuple(f32(v) for v in spectrum(d[15])) and f32(glossy["c"]) == f32(d[16]) and not glossy["remap"]
+    matte = [m for m in want.materials if m["kind"] == abi.MAT_MATTE][-1]
+    assert d[17] == '""' and tuple(f32(v) for v in matte["a"]) == tuple(f32(v) for v in spectrum(d[18])) and f32(matte["c"]) == f32(d[19]) == f32(0.0)
+    metal = next(m for m in want.materials if m["kind"] == abi.MAT_METAL)
+    assert "sampled_spectrum_into_rgb(&COPPER_WAVELENGTHS, &COPPER_N)" in d[20] and "sampled_spectrum_into_rgb(&COPPER_WAVELENGTHS, &COPPER_K)" in d[21]
+    lam, n, k = ol._copper()
+    assert tuple(f32(v) for v in metal["a"]) == tuple(f32(v) for v in ol.sampled_spectrum_into_rgb(lam, n))
+    assert tuple(f32(v) for v in metal["b"]) == tuple(f32(v) for v in ol.sampled_spectrum_into_rgb(lam, k))
+    assert f32(metal["c"]) == f32(d[22]) and bool(metal["remap"]) == (d[23] == "true")
