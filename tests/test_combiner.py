@@ -141,23 +141,27 @@ def test_combiner_interruption_reaches_only_its_caller(yk):
     cam = yk.Camera(sd.camera, fs)
     it = yk.IntegratorType.instantiate(ctx, integ)
     ref, st = it.render_tiles(sc, cam, smp, tiles)
-    assert st.seconds_total > 0.030, "the job must outlast the linger for the interruption to land inside it"
-    fire_after = 0.010 + min(0.010, st.seconds_total / 4)
+    assert st.seconds_total > 0.040, "the job must be long enough for the interruption to land inside it"
+    fire_after = 0.015
     areas = (tiles["x1"].astype(int) - tiles["x0"]) * (tiles["y1"].astype(int) - tiles["y0"])
     offs = np.concatenate([[0], np.cumsum(areas)])
-    comb = yk.Combiner([ctx], linger_us=10000)
-    barrier = threading.Barrier(len(tiles))
+    # max_tiles = all tiles with a long linger: the leader submits the moment every worker has arrived, so ONE submission holds
+    # them all however the host schedules the threads; tile 3's predicate fires 15 ms after the last worker entered: inside the job
+    comb = yk.Combiner([ctx], max_tiles=len(tiles), linger_us=5_000_000)
     polls = [0] * len(tiles)
     results = {}
     import time
 
+    entered = []
+    lock = threading.Lock()
+
     def worker(t):
         def pred():
             polls[t] += 1
-            return t == 3 and time.perf_counter() - t0 > fire_after  # past the 10-ms linger, inside the job
+            return t == 3 and len(entered) == len(tiles) and time.perf_counter() - entered[-1] > fire_after
 
-        barrier.wait()
-        t0 = time.perf_counter()
+        with lock:
+            entered.append(time.perf_counter())
         try:
             px, _ = comb.render(it, sc, cam, smp, yk.FilmTile(tuple(int(v) for v in tiles[t])), cancel=pred)
             results[t] = px
