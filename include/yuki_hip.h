@@ -212,7 +212,7 @@ typedef struct yk_scene yk_scene;
  *     device memory and poisons the launch's queue head, so no wave claims again; every kernel (every
  *     block of the grid-stride ones) reads the device word when it starts and finds its queue
  *     empty; a job of many batches is enqueued two batches at a time.  The call returns after the
- *     drain (~5 ms into a 1.5-s job).  The next render on the context is unaffected.
+ *     drain (3-5 ms into a 1.5-s job; ~10 ms for a context's first interruption).  The next render on the context is unaffected.
  *   - an ASYNCHRONOUS submission (device output, stats == NULL) has returned before the GPU
  *     started: the caller interrupts it with yk_context_interrupt from any thread.
  * The predicate is called from the thread that made the call, never concurrently. */

@@ -73,7 +73,8 @@ struct yk_context {
     // for the context's streams before it clears the word, so that no kernel of the interrupted submission resumes.
     unsigned* cancel_host = nullptr;  // [0] the word, [16] a constant 1: the source of the host's copy into the device word
     const unsigned* cancel_host_dev = nullptr;
-    hipStream_t cancel_stream = nullptr;  // carries that copy past the kernels in flight
+    hipStream_t cancel_stream = nullptr;  // carries that copy past the kernels in flight (made after the context's first interruption)
+    bool want_cancel_stream = false;
     std::atomic<bool> cancel_raised{false};
     // every entry point that touches the context's buffers or streams holds this: calls on one
     // context from several host threads (the reference's tile workers) are serialised

@@ -234,12 +234,14 @@ static void raise_cancel(yk_context* ctx, bool from_render_thread = true) {
     const double t0 = g_debug_cancel ? now_ms() : 0.0;
     ctx->cancel_raised.store(true, std::memory_order_release);
     __atomic_store_n(ctx->cancel_host, 1u, __ATOMIC_RELEASE);
-    // ... and the device word directly (a copy engine's job: it does not queue behind the kernels): k_shade looks at this one only
-    if (from_render_thread && !ctx->cancel_stream && hipStreamCreateWithFlags(&ctx->cancel_stream, hipStreamNonBlocking) != hipSuccess) ctx->cancel_stream = nullptr;
-    const double t1 = g_debug_cancel ? now_ms() : 0.0;
+    // ... and the device word directly (a copy engine's job: it does not queue behind the kernels): k_shade looks at this one only.
+    // The stream that carries the copy is NOT made here — the first interruption of a context relies on the relay wave alone (the
+    // device word is up one traversal launch later at most) and leaves a note; the stream is created when the next submission
+    // clears the word (clear_cancel), off the path whose latency the caller is waiting on.
+    if (from_render_thread && !ctx->cancel_stream) ctx->want_cancel_stream = true;
     if (from_render_thread && ctx->cancel_stream && ctx->counters.p)
         (void)hipMemcpyAsync(error_block(ctx) + YK_CTRL_CANCELLED, ctx->cancel_host + 16, 4, hipMemcpyHostToDevice, ctx->cancel_stream);
-    if (g_debug_cancel) std::fprintf(stderr, "[yk cancel] raise: stream %.3f ms, copy enqueue %.3f ms\n", t1 - t0, now_ms() - t1);
+    if (g_debug_cancel) std::fprintf(stderr, "[yk cancel] raise: %s, %.3f ms\n", ctx->cancel_stream ? "host word + device word" : "host word only (first interruption)", now_ms() - t0);
 }
 
 // Called by a submission before it enqueues anything: if an earlier one was interrupted, whatever it still has on the
@@ -254,6 +256,10 @@ static yk_status clear_cancel(yk_context* ctx) {
     }
     __atomic_store_n(ctx->cancel_host, 0u, __ATOMIC_RELEASE);
     ctx->cancel_raised.store(false, std::memory_order_release);
+    if (ctx->want_cancel_stream && !ctx->cancel_stream) {  // this context gets interrupted: later interruptions also write the device word directly
+        if (hipStreamCreateWithFlags(&ctx->cancel_stream, hipStreamNonBlocking) != hipSuccess) ctx->cancel_stream = nullptr;
+        ctx->want_cancel_stream = false;
+    }
     return YK_OK;
 }
 
