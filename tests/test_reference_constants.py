@@ -183,3 +183,36 @@ def test_pbrt_loader_defaults_match_the_references_text(tmp_path):
     assert tuple(f32(v) for v in metal["a"]) == tuple(f32(v) for v in ol.sampled_spectrum_into_rgb(lam, n))
     assert tuple(f32(v) for v in metal["b"]) == tuple(f32(v) for v in ol.sampled_spectrum_into_rgb(lam, k))
     assert f32(metal["c"]) == f32(d[22]) and bool(metal["remap"]) == (d[23] == "true")
+
+
+def test_permutation_element_is_the_references_statement_by_statement():
+    """stratified.rs:147-178 against oracle/osampler.h and yuki_amd/csrc/yk_rng.h: the loop body as a normalised sequence of
+    (operator, constant-or-shift) steps — multipliers, shift amounts and their order — read out of all three texts."""
+    import re
+
+    def steps(text, start, stop):
+        body = text[text.index(start):]
+        body = body[:body.index(stop)]
+        out = []
+        for line in body.splitlines():
+            line = line.strip().rstrip(";")
+            m = re.match(r"i = i\.wrapping_mul\((.*)\)$", line) or re.match(r"i \*= (.*)$", line)
+            if m:
+                out.append(("mul", m.group(1).replace("u", "").replace(" ", "").lower()))
+                continue
+            m = re.match(r"i \^= (.*)$", line)
+            if m:
+                out.append(("xor", m.group(1).replace(" ", "")))
+                continue
+            m = re.match(r"i &= (.*)$", line)
+            if m:
+                out.append(("and", m.group(1).replace(" ", "")))
+        return out
+
+    ref = steps(open("/root/reference/yuki/src/sampling/stratified.rs").read(), "loop {", "if i < l")
+    orc = steps(open(os.path.join(ROOT, "oracle", "osampler.h")).read().split("inline uint32_t permutation_element")[1], "do {", "} while")
+    rng_h = open(os.path.join(ROOT, "yuki_amd", "csrc", "yk_rng.h")).read()
+    dev = steps(rng_h[rng_h.index("0xe170893d") - 200:], "do {", "} while")  # the loop that holds the first multiplier
+    assert len(ref) == 18 and [s for s in ref if s[0] == "mul"][0] == ("mul", "0xe170893d")
+    assert orc == ref
+    assert dev == ref
