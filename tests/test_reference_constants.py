@@ -216,3 +216,45 @@ def test_permutation_element_is_the_references_statement_by_statement():
     assert len(ref) == 18 and [s for s in ref if s[0] == "mul"][0] == ("mul", "0xe170893d")
     assert orc == ref
     assert dev == ref
+
+
+def test_every_numeric_literal_of_the_paths_files_is_in_the_oracle_and_in_the_product():
+    """A net under "constants verbatim": every non-trivial floating-point literal of the reference files on the path (the
+    roughness polynomial, Oren-Nayar's 0.33 / 0.09 / 0.45, the 0.001 ray offset, 0.9999, the roulette threshold, the camera's
+    near / far, ...) must appear, as the same binary32 value, in the oracle file that restates it and in the product sources."""
+    import re
+
+    REF = "/root/reference/yuki/src/"
+
+    def lits(paths):
+        out = set()
+        for path in paths:
+            text = open(path).read()
+            text = re.sub(r"//[^\n]*", "", text)
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            for m in re.finditer(r"(?<![\w.])(\d[\d_]*\.[\d_]*(?:e-?\d+)?|\d[\d_]*e-?\d+)(?:_?f32|f)?(?![\w.])", text):
+                out.add(float(np.float32(float(m.group(1).replace("_", "")))))
+        return out
+
+    trivial = {float(np.float32(v)) for v in (0, 1, 2, 3, 4, 0.5, 10, 100, 180, 255, 1000)}
+    o = lambda *names: [os.path.join(ROOT, "oracle", n) for n in names]
+    c = lambda *names: [os.path.join(ROOT, "yuki_amd", "csrc", n) for n in names]
+    bsdf = (o("obsdf.h"), c("yk_bsdf.h", "yk_scene.cpp"))
+    geom = (o("oshapes.h", "olights.h"), c("yk_geom.h", "yk_shade.h", "yk_kernels.hip", "yk_trace.hip"))
+    table = {
+        "materials/bsdfs/trowbridge_reitz.rs": bsdf, "materials/bsdfs/oren_nayar.rs": bsdf, "materials/bsdfs/fresnel.rs": bsdf,
+        "materials/bsdfs/microfacet.rs": bsdf, "materials/bsdfs/specular.rs": bsdf, "materials/bsdfs/lambertian.rs": bsdf, "materials/bsdfs/mod.rs": bsdf,
+        "sampling/mod.rs": bsdf,
+        "integrators/path.rs": (o("orender.h"), c("yk_shade.h", "yk_kernels.hip")), "integrators/whitted.rs": (o("orender.h"), c("yk_shade.h", "yk_trace.hip")),
+        "interaction.rs": geom, "visibility.rs": geom, "shapes/triangle.rs": geom, "shapes/sphere.rs": geom,
+        "lights/point_light.rs": geom, "lights/spot_light.rs": geom, "lights/distant_light.rs": geom, "lights/rectangular_light.rs": geom,
+        "camera.rs": (o("orender.h"), c("yk_host.cpp")), "bvh.rs": (o("obvh.h"), c("yk_host.cpp")),
+        "math/bounds.rs": (o("omath.h"), c("yk_math.h", "yk_host.cpp")),
+    }
+    checked = 0
+    for ref_file, (oracle_files, product_files) in table.items():
+        want = lits([REF + ref_file]) - trivial
+        checked += len(want)
+        assert want <= lits(oracle_files), (ref_file, "oracle", sorted(want - lits(oracle_files)))
+        assert want <= lits(product_files), (ref_file, "product", sorted(want - lits(product_files)))
+    assert checked >= 15  # 17 today: the files on the path hold few literals that are not 0, 1, 2 or 0.5
