@@ -55,7 +55,6 @@ struct Request {
     Batch* batch = nullptr;
     bool fired = false;  // this caller's predicate has answered non-zero
     yk_status status = YK_OK;
-    std::string error;
     size_t area() const { return (size_t)(tile.x1 - tile.x0) * (size_t)(tile.y1 - tile.y0); }
 };
 
@@ -282,7 +281,6 @@ yk_status yk_combiner_render_tile(yk_combiner* c, const yk_scene* scene, const y
                 }
                 q->state = Request::DONE;
                 q->status = st;
-                q->error = err;
                 if (st == YK_OK && q->stats) {
                     // counts of a submission are not kept per tile: they are shared out by area, the remainder to the leader — exact in sum,
                     // which is what the reference does with them (render_manager.rs:277-281, window.rs:911-916)
