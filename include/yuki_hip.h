@@ -392,6 +392,9 @@ yk_status yk_camera_rays(yk_context* ctx, const yk_camera* camera, const yk_samp
  * 24 a * b.x, 25 a / b.x, 26 -a, 27 len_sqr (result in out[3k..3k+2]); scalar again: 28 / 29 the sine / cosine of the
  * shared-reduction pair the shading code calls (the same bits as fn 0 / 1) */
 yk_status yk_device_math(yk_context* ctx, int fn, size_t n, const float* a, const float* b, float* out);
+/* The HOST instance of the same scalar functions (fn 0..5, 28, 29 as above; 30 expf): what the loaders, the camera, the spot
+ * light and the roughness remap evaluate on the CPU.  Needs no device. */
+yk_status yk_host_math(int fn, size_t n, const float* a, const float* b, float* out);
 /* Bsdf::f and Bsdf::sample_f on the device for n (wo, wi|u) pairs against one material */
 yk_status yk_bsdf_eval(yk_context* ctx, const yk_material_desc* material, size_t n, const float* n_geom,
                        const float* n_shading, const float* dpdu, const float* wo, const float* wi, float* out_f);

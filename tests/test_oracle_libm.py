@@ -111,3 +111,21 @@ def test_libm_special_values(oracle):
     assert L.orc_logf(0.0) == float("-inf")
     assert L.orc_acosf(1.0) == 0.0 and abs(L.orc_acosf(-1.0) - np.float32(np.pi)) == 0.0
     assert L.orc_atan2f(0.0, -1.0) == np.float32(np.pi) and L.orc_atan2f(1.0, 0.0) == np.float32(np.pi / 2)
+
+
+def test_the_products_host_instance_equals_the_oracle(oracle):
+    """yk_libm.h as the HOST compiles it (the loaders' rotations and CIE fits, the camera's tan, the spot light's cosines, the
+    roughness remap's log) against oracle/olibm.h: every 4,099th binary32 value plus the renderer's ranges, all functions, and the
+    shared-reduction sin / cos pair against the two functions.  No device needed (yk_host_math)."""
+    from yuki_amd import core as yk
+
+    yk.lib()
+    rng = np.random.default_rng(11)
+    x = np.concatenate([np.arange(0, 1 << 32, 4099, dtype=np.uint64).astype(np.uint32).view(np.float32), rng.uniform(-7, 7, 100000).astype(np.float32),
+                        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 0.785398185, 1.0, -1.0], np.float32)])
+    y = rng.permutation(x)
+    for host_fn, oracle_fn in ((0, 0), (1, 1), (2, 2), (3, 3), (4, 4), (5, 5), (28, 0), (29, 1), (30, 6)):
+        got = yk.host_math(host_fn, x, y if host_fn == 5 else None)
+        want = oracle.libm_array(oracle_fn, x, y if oracle_fn == 5 else None)
+        same = _same(got, want)
+        assert same.all(), (host_fn, int((~same).sum()), x[~same][:6])

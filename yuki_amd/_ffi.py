@@ -100,6 +100,7 @@ SYMBOLS = {
     "yk_sampler_sequence": (C.c_int, [vp, C.POINTER(abi.SamplerDesc), C.c_uint16, C.c_uint16, C.c_uint32, vp, C.c_size_t, vp]),
     "yk_camera_rays": (C.c_int, [vp, C.POINTER(abi.CameraMatrices), C.POINTER(abi.SamplerDesc), C.POINTER(abi.Tile), C.c_uint32, vp, vp]),
     "yk_device_math": (C.c_int, [vp, C.c_int, C.c_size_t, vp, vp, vp]),
+    "yk_host_math": (C.c_int, [C.c_int, C.c_size_t, vp, vp, vp]),
     "yk_bsdf_eval": (C.c_int, [vp, C.POINTER(abi.MaterialDesc), C.c_size_t] + [vp] * 6),
     "yk_bsdf_sample": (C.c_int, [vp, C.POINTER(abi.MaterialDesc), C.c_size_t] + [vp] * 6),
     "yk_light_sample": (C.c_int, [vp, C.POINTER(abi.LightDesc), C.c_int32, C.c_size_t] + [vp] * 4),

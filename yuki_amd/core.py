@@ -666,6 +666,15 @@ def device_math(ctx, fn, a, b=None):
     return out
 
 
+def host_math(fn, a, b=None):
+    """yk_host_math: the host instance of yk_libm.h (no device needed)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    bb = None if b is None else np.ascontiguousarray(b, dtype=np.float32)
+    out = np.zeros_like(a)
+    check(lib().yk_host_math(fn, a.size, _p(a), _p(bb), _p(out)))
+    return out
+
+
 def sampler_sequence(ctx, sampler, px, py, sample_index, dims):
     dims = np.ascontiguousarray(dims, dtype=np.uint8)
     out = np.zeros((len(dims), 2), dtype=np.float32)

@@ -184,6 +184,27 @@ yk_status yk_camera_rays(yk_context* ctx, const yk_camera* camera, const yk_samp
     return YK_OK;
 } YK_CATCH(ctx)
 
+yk_status yk_host_math(int fn, size_t n, const float* a, const float* b, float* out) {
+    if (!a || !out) return YK_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < n; ++i) {
+        const float x = a[i], y = b ? b[i] : 0.0f;
+        float sn, cs;
+        switch (fn) {
+            case 0: out[i] = det_sinf(x); break;
+            case 1: out[i] = det_cosf(x); break;
+            case 2: out[i] = det_tanf(x); break;
+            case 3: out[i] = det_logf(x); break;
+            case 4: out[i] = det_acosf(x); break;
+            case 5: out[i] = det_atan2f(x, y); break;
+            case 28: det_sincosf(x, sn, cs); out[i] = sn; break;
+            case 29: det_sincosf(x, sn, cs); out[i] = cs; break;
+            case 30: out[i] = det_expf(x); break;
+            default: return YK_ERR_INVALID_ARGUMENT;
+        }
+    }
+    return YK_OK;
+}
+
 yk_status yk_device_math(yk_context* ctx, int fn, size_t n, const float* a, const float* b, float* out) {
     if (!ctx) return YK_ERR_INVALID_ARGUMENT;
     YK_LOCK(ctx);
